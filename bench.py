@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on N GPUs of one node (one process per GPU).
+
+  python bench.py --gpus 1 --steps K --warmup W [--workload ntt|msm]
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM.
+
+workload ntt (default; BASELINE.json configs[1]): one step = fft(2^20) + ifft(2^20) + coset_fft of an
+  (n+3)-coefficient polynomial on the 8n = 2^23 domain + coset_ifft(2^23), n = 2^20.  Metric: Fr NTT GB/s with
+  the algorithmic bytes 2 * N * 32 per N-point transform.  With N GPUs every rank transforms its own batch
+  (independent polynomials, no collective): weak scaling.
+workload msm (configs[2]): one step = one 2^22-point G1 MSM; with N GPUs the points are range-sharded, every
+  rank sums its range and the 144-byte partial sums are all-gathered over RCCL and added: strong scaling.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of the workload, timed live with HIP
+events on the library's own stream; `cpu_baseline` times the CPU oracle (a C++ restatement of the reference's
+algorithm with the reference's parallel structure; the reference itself is Rust and cannot be built here) on a
+bounded sample of the same workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FR_TOP = np.uint64(0x73eda753299d7d48)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+
+
+def random_fr(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    a[:, 3] %= FR_TOP
+    return a
+
+
+def to_dev(a, device):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(device)
+
+
+def dist_setup(n_gpus):
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == n_gpus, "launch with torch.distributed.run --nproc-per-node %d" % n_gpus
+    return rank, world, local
+
+
+def barrier(world, device):
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value, world, device):
+    import torch
+    if world == 1:
+        return value
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+# ---- NTT workload ------------------------------------------------------------------------------------------
+LOG_N = 20
+NTT_STEP_TRANSFORMS = [(0, LOG_N), (1, LOG_N), (2, LOG_N + 3), (3, LOG_N + 3)]   # (mode, log size)
+
+
+def ntt_step_bytes():
+    return sum(2 * (1 << lg) * 32 for _, lg in NTT_STEP_TRANSFORMS)
+
+
+def run_ntt(args, rank, world, local, device):
+    import torch
+    import zkvm_amd
+    ctx = zkvm_amd.Context(local)
+    n = 1 << LOG_N
+    evals = to_dev(random_fr(n, 1 + rank), device)                 # seed 1: forward / inverse input
+    coeffs = to_dev(random_fr(n + 3, 2 + 100 * rank), device)      # seed 2: (n+3)-coefficient polynomial
+    buf_n = torch.empty((n, 4), dtype=torch.int64, device=device)
+    buf_8n = torch.empty((8 * n, 4), dtype=torch.int64, device=device)
+
+    def step():
+        ctx.ntt(evals, LOG_N, zkvm_amd.FFT, out=buf_n)
+        ctx.ntt(buf_n, LOG_N, zkvm_amd.IFFT, out=buf_n)
+        ctx.ntt(coeffs, LOG_N + 3, zkvm_amd.COSET_FFT, out=buf_8n)
+        ctx.ntt(buf_8n, LOG_N + 3, zkvm_amd.COSET_IFFT, out=buf_8n)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    ctx.sync()
+    barrier(world, device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    barrier(world, device)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, device)
+
+    # the round trip must return the input (cheap end-to-end sanity check inside the bench itself)
+    assert torch.equal(buf_n, evals), "ifft(fft(x)) != x"
+    assert torch.equal(buf_8n[:n + 3], coeffs) and not bool(buf_8n[n + 3:].any()), "coset round trip failed"
+
+    out = {}
+    if rank == 0:
+        # dominant kernel: ntt_pass_kernel on the 2^23 coset transforms (3 launches per transform).  HIP events on
+        # the library's stream around `reps` coset_fft(2^23) calls.
+        reps, passes = 10, 3
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(reps):
+            ctx.ntt(coeffs, LOG_N + 3, zkvm_amd.COSET_FFT, out=buf_8n)
+        ms = ctx.timer_stop()
+        launch_ms = ms / (reps * passes)
+        alg_bytes_per_launch = 2 * (8 * n) * 32 / passes
+        achieved = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "ntt_pass_kernel (2^23-point coset_fft, %d launches per transform)" % passes,
+                           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "avg_launch_ms": round(launch_ms, 4),
+                           "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
+                           "note": "VALU-bound (one Fr product per butterfly, ~300 VALU instructions each); see DESIGN.md"}
+        out["per_transform_ms"] = {}
+        for mode, lg, name in ((0, LOG_N, "fft_2^20"), (1, LOG_N, "ifft_2^20"), (2, LOG_N + 3, "coset_fft_2^23"),
+                               (3, LOG_N + 3, "coset_ifft_2^23")):
+            src, dst = (evals, buf_n) if lg == LOG_N else (coeffs if mode == 2 else buf_8n, buf_8n)
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(5):
+                ctx.ntt(src, lg, mode, out=dst)
+            out["per_transform_ms"][name] = round(ctx.timer_stop() / 5, 4)
+    ctx.sync()
+    value = world * args.steps * ntt_step_bytes() / elapsed / 1e9
+    return value, elapsed, out, ctx
+
+
+def cpu_baseline_ntt():
+    """Serial radix-2 FFT of the oracle (the reference's best_fft is serial: plonk/src/fft/domain.rs:286-340) on
+    one 2^20 forward, one 2^20 inverse and one 2^23 coset transform."""
+    from oracle import pyoracle as orc
+    n = 1 << LOG_N
+    x = random_fr(n, 1)
+    c = random_fr(n + 3, 2)
+    secs = 0.0
+    nbytes = 0
+    for mode, data, size in (("fft", x, n), ("ifft", x, n), ("coset_fft", c, 8 * n)):
+        _, s = orc.fft(mode, data, size, with_time=True)
+        secs += s
+        nbytes += 2 * size * 32
+    return {"value": round(nbytes / secs / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "fft(2^20) + ifft(2^20) + coset_fft(2^20+3 coeffs -> 2^23), serial radix-2 as in the reference; %.1f s" % secs}
+
+
+# ---- MSM workload ------------------------------------------------------------------------------------------
+MSM_LOG = 22
+
+
+def synthetic_points(ctx, n, device):
+    """n distinct G1 points for throughput runs: k_i * G for pseudo-random 64-bit k_i would need n scalar
+    multiplications; instead the oracle makes 2^12 consecutive multiples of G on the CPU and the device table is
+    filled by tiling them (duplicates do not change the work per addition: the formulas are complete)."""
+    import torch
+    from oracle import pyoracle as orc
+    base, _ = orc.g1_multiples_of_generator(1, 1 << 12)
+    reps = (n + (1 << 12) - 1) >> 12
+    t = to_dev(base, device).repeat(reps, 1)[:n].contiguous()
+    return t
+
+
+def run_msm(args, rank, world, local, device):
+    import torch
+    import zkvm_amd
+    ctx = zkvm_amd.Context(local)
+    n_total = 1 << MSM_LOG
+    shard = n_total // world
+    pts = synthetic_points(ctx, n_total, device)
+    ctx.srs_load(pts[rank * shard:(rank + 1) * shard].contiguous())
+    del pts
+    scalars = to_dev(random_fr(n_total, 3)[rank * shard:(rank + 1) * shard], device)   # seed 3: uniform scalars
+
+    def step():
+        part = ctx.msm_partial(scalars, 0)
+        if world > 1:
+            import torch.distributed as dist
+            mine = torch.from_numpy(part.view(np.int64)).to(device)
+            gathered = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            parts = np.stack([g.cpu().numpy().view(np.uint64) for g in gathered])
+        else:
+            parts = part.reshape(1, 18)
+        return zkvm_amd.g1_sum_to_affine(parts)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    barrier(world, device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier(world, device)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, device)
+    out = {}
+    if rank == 0:
+        reps = 3
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(reps):
+            ctx.msm_kernels(scalars)
+        ms = ctx.timer_stop() / reps
+        out["msm_device_phase_ms"] = round(ms, 3)
+        out["result_x0"] = hex(int(res[0][0]))
+    value = args.steps * n_total / elapsed / 1e6
+    return value, elapsed, out, ctx
+
+
+def cpu_baseline_msm():
+    from oracle import pyoracle as orc
+    n = 1 << 16
+    pts, _ = orc.g1_multiples_of_generator(1, 1 << 12)
+    pts = np.tile(pts, (n >> 12, 1))
+    sc = random_fr(n, 3)
+    cores = min(os.cpu_count() or 1, 16)
+    _, secs = orc.msm(pts, sc, threads=cores, with_time=True)
+    return {"value": round(n / secs / 1e6, 4), "unit": "Mpts/s", "cores": cores, "kind": "port",
+            "sample": "one 2^16-point msm_variable_base (window-parallel as the reference's rayon map); %.1f s" % secs}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="ntt", choices=["ntt", "msm"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank, world, local = dist_setup(args.gpus)
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    if args.workload == "ntt":
+        value, elapsed, extra, ctx = run_ntt(args, rank, world, local, device)
+        line = {"metric": "Fr NTT GB/s", "unit": "GB/s", "scaling": "weak", "dtype": "u32x8 (255-bit Fr, Montgomery)",
+                "config": {"workload": "fft(2^20) + ifft(2^20) + coset_fft(2^20+3 -> 2^23) + coset_ifft(2^23) per step, "
+                                       "bit-exact vs EvaluationDomain", "n": 1 << LOG_N,
+                           "algorithmic_bytes_per_step": ntt_step_bytes(), "parallelism": "independent polynomials per GPU"}}
+    else:
+        value, elapsed, extra, ctx = run_msm(args, rank, world, local, device)
+        line = {"metric": "BLS12-381 G1 MSM Mpts/s", "unit": "Mpts/s", "scaling": "strong",
+                "dtype": "u32x12 (381-bit Fq, Montgomery)",
+                "config": {"workload": "KZG10 commit: 2^%d-point G1 MSM, uniform scalars" % MSM_LOG, "n": 1 << MSM_LOG,
+                           "parallelism": "point-range shards, 144-byte partial sums all-gathered over RCCL"}}
+    if rank == 0:
+        line.update({"value": round(value, 3), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                     "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "vs_baseline": None,
+                     "data": "synthetic (seeded uniform Fr; SRS-shaped point table)"})
+        line.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_ntt() if args.workload == "ntt" else cpu_baseline_msm()
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

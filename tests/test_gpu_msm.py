@@ -1,0 +1,136 @@
+"""GPU parity: zkgpu_msm / zkgpu_commit against the CPU oracle's msm_variable_base + affine conversion."""
+import os
+
+import numpy as np
+import pytest
+
+import model as M
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import zkvm_amd
+    c = zkvm_amd.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_affine(orc, pts, sc, inf=None):
+    return orc.g1_to_affine(orc.msm(pts, sc, inf=inf, threads=8))
+
+
+def check(ctx, orc, pts, sc, inf=None):
+    ctx.srs_load(pts, inf)
+    got_xy, got_inf = ctx.msm(sc)
+    want_xy, want_inf = oracle_affine(orc, pts, sc, inf)
+    assert got_inf == want_inf
+    assert np.array_equal(got_xy, want_xy)
+
+
+def test_msm_k_times_g_vectors(ctx, orc):
+    """All bases = G: the result is (sum of scalars) * G, pinned by the reference's k*G vectors."""
+    import zkvm_amd
+    data = open(os.path.join(GOLDEN, "g1_compressed_valid_test_vectors.dat"), "rb").read()
+    gxy, _ = orc.g1_to_affine(orc.g1_generator())
+    for n, scalars in ((1, [100]), (5, [0, 1, 1, 3, 7]), (40, list(range(40))), (33, [1] * 33), (64, [0] * 63 + [999])):
+        ctx.srs_load(np.tile(gxy, (n, 1)))
+        xy, inf = ctx.msm(M.fr_vec_to_mont(scalars))
+        k = sum(scalars)
+        assert zkvm_amd.g1_compress(xy, inf) == data[48 * k:48 * k + 48], (n, k)
+    # sum == 0 -> identity, encoded as the reference's affine identity
+    ctx.srs_load(np.tile(gxy, (3, 1)))
+    xy, inf = ctx.msm(M.fr_vec_to_mont([0, 0, 0]))
+    assert inf == 1 and zkvm_amd.g1_compress(xy, inf) == data[:48]
+    xy, inf = ctx.msm(M.fr_vec_to_mont([5, M.R_MOD - 5, 0]))
+    assert inf == 1
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 100, 1000, 5000])
+def test_msm_random_small(ctx, orc, n):
+    pts, _ = orc.g1_multiples_of_generator(1, n)
+    sc = M.random_fr_mont(n, 50 + n)
+    check(ctx, orc, pts, sc)
+
+
+def test_msm_edge_scalars(ctx, orc):
+    n = 2048
+    pts, _ = orc.g1_multiples_of_generator(3, n)
+    r_minus_1 = M.fr_to_mont(M.R_MOD - 1)
+    check(ctx, orc, pts, np.tile(r_minus_1, (n, 1)))                      # all r-1: one giant bucket per window
+    check(ctx, orc, pts, np.tile(M.fr_to_mont(1), (n, 1)))                # all ones
+    check(ctx, orc, pts, np.tile(M.random_fr_mont(1, 9), (n, 1)))         # all equal
+    check(ctx, orc, pts, np.zeros((n, 4), np.uint64))                     # all zero -> identity
+    # witness-like: 30% zeros, 20% ones, 20% < 2^16, 30% uniform
+    rng = np.random.Generator(np.random.PCG64(4))
+    sc = M.random_fr_mont(n, 4)
+    kind = rng.random(n)
+    small = M.fr_vec_to_mont([int(v) for v in rng.integers(0, 1 << 16, size=n)])
+    sc[kind < 0.3] = 0
+    sc[(kind >= 0.3) & (kind < 0.5)] = M.fr_to_mont(1)
+    mask = (kind >= 0.5) & (kind < 0.7)
+    sc[mask] = small[mask]
+    check(ctx, orc, pts, sc)
+
+
+def test_msm_infinity_points_and_truncation(ctx, orc):
+    pts, inf = orc.g1_multiples_of_generator(0, 64)     # element 0 is the point at infinity
+    sc = M.random_fr_mont(64, 8)
+    check(ctx, orc, pts, sc, inf)
+    # more scalars than points: truncated like the reference's zip
+    pts, _ = orc.g1_multiples_of_generator(1, 50)
+    sc = M.random_fr_mont(80, 12)
+    ctx.srs_load(pts)
+    got_xy, got_inf = ctx.msm(sc)
+    want_xy, want_inf = oracle_affine(orc, pts, sc[:50])
+    assert got_inf == want_inf and np.array_equal(got_xy, want_xy)
+    # fewer scalars than points
+    got_xy, _ = ctx.msm(sc[:20])
+    want_xy, _ = oracle_affine(orc, pts[:20], sc[:20])
+    assert np.array_equal(got_xy, want_xy)
+
+
+def test_commit_degree_checks(ctx, orc):
+    import zkvm_amd
+    pts, _ = orc.g1_multiples_of_generator(1, 16)
+    ck = zkvm_amd.CommitKey(ctx, pts)
+    assert ck.max_degree() == 15
+    with pytest.raises(zkvm_amd.PolynomialDegreeIsZero):
+        ck.commit(np.zeros((4, 4), np.uint64))
+    with pytest.raises(zkvm_amd.PolynomialDegreeIsZero):
+        ck.commit(M.fr_vec_to_mont([5, 0, 0]))
+    with pytest.raises(zkvm_amd.PolynomialDegreeTooLarge):
+        ck.commit(M.random_fr_mont(17, 1))
+    poly = M.random_fr_mont(16, 2)
+    xy, inf = ck.commit(poly)
+    want_xy, want_inf = oracle_affine(orc, pts, poly)
+    assert inf == want_inf and np.array_equal(xy, want_xy)
+    # leading zeros beyond the key length are fine: degree is what counts
+    padded = np.concatenate([poly, np.zeros((8, 4), np.uint64)])
+    xy2, _ = ck.commit(padded)
+    assert np.array_equal(xy2, xy)
+
+
+def test_msm_2_16_device_scalars_and_sharding(ctx, orc):
+    """65536 distinct points (tau-powers SRS), scalars resident in HBM; the two half-range partial sums add up to
+    the full result (the point-range sharding used across GPUs)."""
+    import torch
+    import zkvm_amd
+    n = 1 << 16
+    tau = M.fr_to_mont(0x1234567890abcdef1234567890abcdef % M.R_MOD)
+    pts, _ = orc.srs_powers(orc.g1_generator(), tau, 256)
+    # a 2^16 SRS by scalar multiplication would take minutes on the CPU: use consecutive multiples instead
+    pts, _ = orc.g1_multiples_of_generator(7, n)
+    sc = M.random_fr_mont(n, 3)
+    ctx.srs_load(pts)
+    sd = torch.from_numpy(sc.view(np.int64)).cuda()
+    got_xy, got_inf = ctx.msm(sd)
+    want_xy, want_inf = oracle_affine(orc, pts, sc)
+    assert got_inf == want_inf and np.array_equal(got_xy, want_xy)
+    half = n // 2
+    p0 = ctx.msm_partial(sd[:half].contiguous(), 0)
+    p1 = ctx.msm_partial(sd[half:].contiguous(), half)
+    xy, inf = zkvm_amd.g1_sum_to_affine(np.stack([p0, p1]))
+    assert inf == want_inf and np.array_equal(xy, want_xy)

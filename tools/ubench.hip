@@ -1,0 +1,161 @@
+// Micro-benchmarks behind the VALU ceilings quoted in DESIGN.md: issue cost of the integer / f64 instructions
+// the field arithmetic is made of, and whole-chip throughput of the Fr and Fq Montgomery products.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I zkvm_amd/csrc tools/ubench.hip -o tools/ubench && tools/ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "ff.cuh"
+
+using namespace zk;
+
+#define CHECK(x)                                                                       \
+    do {                                                                               \
+        hipError_t e = (x);                                                            \
+        if (e != hipSuccess) {                                                         \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+            return 1;                                                                  \
+        }                                                                              \
+    } while (0)
+
+static const int ITERS = 4096;
+
+// Each kernel runs a chain of 8 independent copies of one instruction per iteration (so issue rate, not latency,
+// is measured) and reports shader cycles per wave-instruction through s_memtime.
+#define RATE_KERNEL(NAME, BODY)                                                                    \
+    __global__ void NAME(uint64_t *cycles, uint32_t *sink, uint32_t seed) {                        \
+        uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3;        \
+        uint32_t a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;            \
+        uint64_t q0 = a0, q1 = a1, q2 = a2, q3 = a3, q4 = a4, q5 = a5, q6 = a6, q7 = a7;            \
+        double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;              \
+        uint32_t m = seed | 1;                                                                      \
+        double dm = 1.0000001;                                                                      \
+        (void)q0; (void)d0; (void)dm; (void)m;                                                      \
+        uint64_t t0 = __builtin_amdgcn_s_memtime();                                                 \
+        for (int i = 0; i < ITERS; i++) { BODY }                                                    \
+        uint64_t t1 = __builtin_amdgcn_s_memtime();                                                 \
+        uint32_t s = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                         \
+        s ^= (uint32_t)(q0 ^ q1 ^ q2 ^ q3 ^ q4 ^ q5 ^ q6 ^ q7);                                     \
+        s ^= (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);                                     \
+        sink[blockIdx.x * blockDim.x + threadIdx.x] = s;                                            \
+        if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;                                         \
+    }
+
+#define X8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+
+#define OP_MAD64(k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q##k) : "v"(a##k), "v"(m) : "vcc");
+#define OP_MULLO(k) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a##k) : "v"(m));
+#define OP_MULHI(k) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a##k) : "v"(m));
+#define OP_ADD(k) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a##k) : "v"(m) : "vcc");
+#define OP_ADDC(k) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a##k) : "v"(m) : "vcc");
+#define OP_ADD64(k) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q##k) : "v"(q7));
+#define OP_MAD24(k) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a##k) : "v"(m));
+#define OP_FMA64(k) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(d##k) : "v"(dm));
+#define OP_FMA32(k) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a##k) : "v"(m));
+#define OP_MAD32(k) asm volatile("v_mad_u32_u24 %0, %0, %1, %0\n\tv_mul_hi_u32_u24 %0, %0, %1" : "+v"(a##k) : "v"(m));
+
+RATE_KERNEL(k_mad64, X8(OP_MAD64))
+RATE_KERNEL(k_mullo, X8(OP_MULLO))
+RATE_KERNEL(k_mulhi, X8(OP_MULHI))
+RATE_KERNEL(k_add, X8(OP_ADD))
+RATE_KERNEL(k_addc, X8(OP_ADDC))
+RATE_KERNEL(k_add64, X8(OP_ADD64))
+RATE_KERNEL(k_mad24, X8(OP_MAD24))
+RATE_KERNEL(k_fma64, X8(OP_FMA64))
+RATE_KERNEL(k_fma32, X8(OP_FMA32))
+
+template <class F>
+__global__ void k_field_mul(F *out, uint32_t iters) {
+    F a, b;
+    for (int i = 0; i < F::N; i++) {
+        a.v[i] = threadIdx.x * 7 + i + 1 + blockIdx.x;
+        b.v[i] = threadIdx.x * 13 + i * 3 + 2;
+    }
+    a.v[F::N - 1] &= 0x0fffffff;
+    b.v[F::N - 1] &= 0x0fffffff;
+    for (uint32_t i = 0; i < iters; i++) {
+        a = F::mul(a, b);
+        b = F::mul(b, a);
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = F::add(a, b);
+}
+
+template <class K>
+static int run_rate(const char *name, K kernel, int waves_per_simd) {
+    // one block of 256*waves_per_simd threads per CU-ish; cycles reported by wave 0 of each block
+    const int blocks = 256, threads = 256 * waves_per_simd > 1024 ? 1024 : 256 * waves_per_simd;
+    uint64_t *cyc;
+    uint32_t *sink;
+    CHECK(hipMalloc(&cyc, blocks * 8));
+    CHECK(hipMalloc(&sink, (size_t)blocks * threads * 4));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, 0, cyc, sink, 12345u);
+    CHECK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, 0, cyc, sink, 777u);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<uint64_t> h(blocks);
+    CHECK(hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost));
+    double avg = 0;
+    for (auto v : h) avg += (double)v;
+    avg /= blocks;
+    const double insts_per_wave = (double)ITERS * 8;
+    const double waves_on_simd = threads / 256.0;  // 4 SIMDs per CU, one block per CU
+    // s_memtime ticks at a constant 100 MHz on this part; convert with the wall time of the launch instead
+    double total_wave_insts = insts_per_wave * blocks * (threads / 64.0);
+    double ginst = total_wave_insts / (ms * 1e-3) / 1e9;
+    printf("%-10s waves/SIMD=%d  memtime ticks/block=%.0f  launch %.3f ms  -> %.2f G wave-inst/s chip-wide, "
+           "%.3f ns per wave-inst per SIMD\n",
+           name, (int)waves_on_simd, avg, ms, ginst, (ms * 1e6) / (insts_per_wave * waves_on_simd));
+    CHECK(hipFree(cyc));
+    CHECK(hipFree(sink));
+    return 0;
+}
+
+template <class F>
+static int run_field(const char *name, int threads_per_block, int blocks) {
+    F *out;
+    const uint32_t iters = 2000;
+    CHECK(hipMalloc(&out, (size_t)blocks * threads_per_block * sizeof(F)));
+    hipLaunchKernelGGL(k_field_mul<F>, dim3(blocks), dim3(threads_per_block), 0, 0, out, 10u);
+    CHECK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_field_mul<F>, dim3(blocks), dim3(threads_per_block), 0, 0, out, iters);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    double muls = 2.0 * iters * blocks * threads_per_block;
+    printf("%-10s %d x %d threads: %.3f ms -> %.2f G mul/s\n", name, blocks, threads_per_block, ms, muls / (ms * 1e-3) / 1e9);
+    CHECK(hipFree(out));
+    return 0;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s, %d CUs, clock %d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
+    for (int w = 1; w <= 4; w *= 2) {
+        if (run_rate("fma_f32", k_fma32, w)) return 1;
+        if (run_rate("add_co", k_add, w)) return 1;
+        if (run_rate("addc_co", k_addc, w)) return 1;
+        if (run_rate("add_u64", k_add64, w)) return 1;
+        if (run_rate("mad_u24", k_mad24, w)) return 1;
+        if (run_rate("mul_lo", k_mullo, w)) return 1;
+        if (run_rate("mul_hi", k_mulhi, w)) return 1;
+        if (run_rate("mad_u64", k_mad64, w)) return 1;
+        if (run_rate("fma_f64", k_fma64, w)) return 1;
+    }
+    for (int tpb : {256, 512, 1024}) {
+        if (run_field<Fr>("Fr::mul", tpb, 2048)) return 1;
+        if (run_field<Fq>("Fq::mul", tpb, 2048)) return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,86 @@
+"""ctypes binding of zkvm_amd/libzkgpu.so (the C boundary declared in include/zkgpu.h).
+
+The library is hand-written HIP for gfx950; there is no CPU fallback.  Loading succeeds without a GPU (so
+that the symbols can be checked), but zkgpu_init fails with ZKGPU_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkgpu.so")
+
+ERRORS = {
+    -1: "ZKGPU_ERR_INVALID_ARG", -2: "ZKGPU_ERR_HIP", -3: "ZKGPU_ERR_NO_DEVICE", -4: "ZKGPU_ERR_DOMAIN_SIZE",
+    -5: "ZKGPU_ERR_DEGREE_ZERO", -6: "ZKGPU_ERR_DEGREE_LARGE", -7: "ZKGPU_ERR_NOT_LOADED", -8: "ZKGPU_ERR_OOM",
+    -9: "ZKGPU_ERR_QUOTIENT_SHAPE", -10: "ZKGPU_ERR_INTERNAL",
+}
+
+
+class ZkGpuError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "ZKGPU_ERR"), code, message))
+        self.code = code
+
+
+class Domain(C.Structure):
+    _fields_ = [("size", C.c_uint64), ("log_size_of_group", C.c_uint32), ("size_as_field_element", C.c_uint64 * 4),
+                ("size_inv", C.c_uint64 * 4), ("group_gen", C.c_uint64 * 4), ("group_gen_inv", C.c_uint64 * 4),
+                ("generator_inv", C.c_uint64 * 4)]
+
+
+def build(force=False):
+    """Compile libzkgpu.so for gfx950 with the Makefile in csrc/ (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"])
+    return LIB_PATH
+
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/zkgpu.h one to one
+_P = C.c_void_p
+SIGNATURES = {
+    "zkgpu_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "zkgpu_destroy": (None, [_P]),
+    "zkgpu_last_error": (C.c_char_p, [_P]),
+    "zkgpu_sync": (C.c_int, [_P]),
+    "zkgpu_device_bytes": (C.c_size_t, [_P]),
+    "zkgpu_timer_start": (C.c_int, [_P]),
+    "zkgpu_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "zkgpu_domain_new": (C.c_int, [C.c_uint64, C.POINTER(Domain)]),
+    "zkgpu_ntt": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.c_int]),
+    "zkgpu_ntt_dev": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_uint32, C.c_int]),
+    "zkgpu_srs_load": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "zkgpu_srs_load_dev": (C.c_int, [_P, _P, C.c_size_t]),
+    "zkgpu_msm": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
+    "zkgpu_msm_dev": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
+    "zkgpu_msm_partial_dev": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P]),
+    "zkgpu_g1_sum_to_affine": (C.c_int, [_P, C.c_size_t, _P, _P]),
+    "zkgpu_msm_kernels_dev": (C.c_int, [_P, _P, C.c_size_t]),
+    "zkgpu_commit": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
+    "zkgpu_g1_compress": (C.c_int, [_P, C.c_uint8, _P]),
+}
+
+
+def lib():
+    """The loaded library.  Raises if libzkgpu.so has not been built: the product never degrades to a CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("zkvm_amd/libzkgpu.so is missing: build it with __graft_entry__.build() or "
+                               "`make -C zkvm_amd/csrc` (hipcc, gfx950)")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; a process must not run two HIP runtimes (the second
+        # one finds no GPU).  Importing torch first makes the loader resolve this library's libamdhip64.so.7
+        # dependency to the copy torch has already mapped, so device pointers are shared between the two.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib

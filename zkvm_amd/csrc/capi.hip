@@ -1,0 +1,292 @@
+// extern "C" boundary (include/zkgpu.h): context management and argument checking around the engines.
+#include "../../include/zkgpu.h"
+#include "common.hpp"
+#include "msm.hpp"
+#include "ntt.hpp"
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+using namespace zk;
+
+struct zkgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::unique_ptr<NttEngine> ntt;
+    std::unique_ptr<MsmEngine> msm;
+    DevBuf stage_a, stage_b;  // staging for the host-pointer entry points
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string last_error;
+};
+
+static thread_local std::string g_init_error;
+
+// Runs `body`, mapping exceptions to error codes; never lets one cross the C boundary.
+template <class F>
+static int guarded(zkgpu_ctx *ctx, F body) {
+    if (!ctx) return ZKGPU_ERR_INVALID_ARG;
+    try {
+        ZK_HIP(hipSetDevice(ctx->device));
+        body();
+        return ZKGPU_OK;
+    } catch (const ZkError &e) {
+        ctx->last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        ctx->last_error = "host allocation failed";
+        return ZKGPU_ERR_OOM;
+    } catch (const std::exception &e) {
+        ctx->last_error = e.what();
+        return ZKGPU_ERR_INTERNAL;
+    } catch (...) {
+        ctx->last_error = "unknown error";
+        return ZKGPU_ERR_INTERNAL;
+    }
+}
+
+static void fr_to_u64(const Fr &a, uint64_t out[4]) { memcpy(out, a.v, 32); }
+
+static void affine_out(const G1Proj &p, uint64_t out_xy[12], uint8_t *out_infinity) {
+    Fq x, y;
+    bool inf;
+    g1_to_affine(p, x, y, inf);
+    memcpy(out_xy, x.v, 48);
+    memcpy(out_xy + 6, y.v, 48);
+    if (out_infinity) *out_infinity = inf ? 1 : 0;
+}
+
+extern "C" {
+
+int zkgpu_init(zkgpu_ctx **out, int device_id) {
+    if (!out) return ZKGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        g_init_error = "no HIP device available (this library has no CPU fallback)";
+        return ZKGPU_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n_dev) {
+        g_init_error = "device id out of range";
+        return ZKGPU_ERR_INVALID_ARG;
+    }
+    zkgpu_ctx *ctx = new (std::nothrow) zkgpu_ctx();
+    if (!ctx) return ZKGPU_ERR_OOM;
+    ctx->device = device_id;
+    try {
+        ZK_HIP(hipSetDevice(device_id));
+        ZK_HIP(hipStreamCreate(&ctx->stream));
+        ZK_HIP(hipEventCreate(&ctx->ev0));
+        ZK_HIP(hipEventCreate(&ctx->ev1));
+        ctx->ntt.reset(new NttEngine(ctx->stream));
+        ctx->msm.reset(new MsmEngine(ctx->stream));
+    } catch (const ZkError &err) {
+        g_init_error = err.what();
+        int code = err.code;
+        delete ctx;
+        return code;
+    }
+    *out = ctx;
+    return ZKGPU_OK;
+}
+
+void zkgpu_destroy(zkgpu_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->ntt.reset();
+    ctx->msm.reset();
+    ctx->stage_a.release();
+    ctx->stage_b.release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *zkgpu_last_error(const zkgpu_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_init_error.c_str(); }
+
+int zkgpu_sync(zkgpu_ctx *ctx) {
+    return guarded(ctx, [&] { ZK_HIP(hipStreamSynchronize(ctx->stream)); });
+}
+
+size_t zkgpu_device_bytes(const zkgpu_ctx *ctx) {
+    if (!ctx) return 0;
+    return ctx->ntt->device_bytes() + ctx->msm->device_bytes() + ctx->stage_a.cap + ctx->stage_b.cap;
+}
+
+int zkgpu_timer_start(zkgpu_ctx *ctx) {
+    return guarded(ctx, [&] { ZK_HIP(hipEventRecord(ctx->ev0, ctx->stream)); });
+}
+int zkgpu_timer_stop(zkgpu_ctx *ctx, float *elapsed_ms) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(elapsed_ms != nullptr, ZKGPU_ERR_INVALID_ARG, "timer_stop: null output");
+        ZK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+        ZK_HIP(hipEventSynchronize(ctx->ev1));
+        ZK_HIP(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    });
+}
+
+int zkgpu_domain_new(uint64_t num_coeffs, zkgpu_domain *out) {
+    if (!out) return ZKGPU_ERR_INVALID_ARG;
+    try {
+        Domain d = Domain::make(num_coeffs);
+        out->size = d.size;
+        out->log_size_of_group = d.log_size;
+        fr_to_u64(d.size_as_field_element, out->size_as_field_element);
+        fr_to_u64(d.size_inv, out->size_inv);
+        fr_to_u64(d.group_gen, out->group_gen);
+        fr_to_u64(d.group_gen_inv, out->group_gen_inv);
+        fr_to_u64(d.generator_inv, out->generator_inv);
+        return ZKGPU_OK;
+    } catch (const ZkError &e) {
+        g_init_error = e.what();
+        return e.code;
+    }
+}
+
+int zkgpu_ntt_dev(zkgpu_ctx *ctx, const void *in_dev, size_t len_in, void *out_dev, uint32_t log_n, int mode) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(mode >= 0 && mode <= 3, ZKGPU_ERR_INVALID_ARG, "ntt: mode must be 0..3");
+        ctx->ntt->transform((NttMode)mode, static_cast<const Fr *>(in_dev), len_in, static_cast<Fr *>(out_dev), log_n);
+    });
+}
+
+int zkgpu_ntt(zkgpu_ctx *ctx, uint64_t *data, size_t len_in, uint32_t log_n, int mode) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(mode >= 0 && mode <= 3, ZKGPU_ERR_INVALID_ARG, "ntt: mode must be 0..3");
+        ZK_REQUIRE(data != nullptr, ZKGPU_ERR_INVALID_ARG, "ntt: null data");
+        ZK_REQUIRE(log_n < 32, ZKGPU_ERR_DOMAIN_SIZE, "InvalidEvalDomainSize: log2(size) must be below 32");
+        const size_t n = (size_t)1 << log_n;
+        if (len_in > n) len_in = n;
+        ctx->stage_a.reserve(n * sizeof(Fr));
+        if (len_in)
+            ZK_HIP(hipMemcpyAsync(ctx->stage_a.p, data, len_in * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        ctx->ntt->transform((NttMode)mode, ctx->stage_a.as<Fr>(), len_in, ctx->stage_a.as<Fr>(), log_n);
+        ZK_HIP(hipMemcpyAsync(data, ctx->stage_a.p, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int zkgpu_srs_load(zkgpu_ctx *ctx, const uint64_t *xy, const uint8_t *infinity, size_t n_points) {
+    return guarded(ctx, [&] { ctx->msm->load_points(xy, infinity, n_points); });
+}
+int zkgpu_srs_load_dev(zkgpu_ctx *ctx, const void *xy_dev, size_t n_points) {
+    return guarded(ctx, [&] { ctx->msm->load_points_device(xy_dev, n_points); });
+}
+
+static void msm_checked(zkgpu_ctx *ctx, const Fr *scalars_dev, size_t n, uint64_t out_xy[12], uint8_t *out_infinity) {
+    ZK_REQUIRE(out_xy != nullptr, ZKGPU_ERR_INVALID_ARG, "msm: null output");
+    ZK_REQUIRE(ctx->msm->n_points() > 0, ZKGPU_ERR_NOT_LOADED, "msm: no SRS loaded");
+    if (n > ctx->msm->n_points()) n = ctx->msm->n_points();  // the reference's zip stops at the shorter slice
+    G1Proj sum = n ? ctx->msm->msm(scalars_dev, n, 0) : G1Proj::identity();
+    affine_out(sum, out_xy, out_infinity);
+}
+
+int zkgpu_msm_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, uint64_t out_xy[12], uint8_t *out_infinity) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(scalars_dev != nullptr || n == 0, ZKGPU_ERR_INVALID_ARG, "msm: null scalars");
+        msm_checked(ctx, static_cast<const Fr *>(scalars_dev), n, out_xy, out_infinity);
+    });
+}
+
+int zkgpu_msm(zkgpu_ctx *ctx, const uint64_t *scalars, size_t n, uint64_t out_xy[12], uint8_t *out_infinity) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(scalars != nullptr || n == 0, ZKGPU_ERR_INVALID_ARG, "msm: null scalars");
+        size_t m = n;
+        if (m > ctx->msm->n_points()) m = ctx->msm->n_points();
+        ctx->stage_b.reserve((m ? m : 1) * sizeof(Fr));
+        if (m) ZK_HIP(hipMemcpyAsync(ctx->stage_b.p, scalars, m * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        msm_checked(ctx, ctx->stage_b.as<Fr>(), m, out_xy, out_infinity);
+    });
+}
+
+int zkgpu_msm_partial_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, size_t base, uint64_t out_xyz[18]) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(out_xyz != nullptr, ZKGPU_ERR_INVALID_ARG, "msm: null output");
+        ZK_REQUIRE(scalars_dev != nullptr || n == 0, ZKGPU_ERR_INVALID_ARG, "msm: null scalars");
+        ZK_REQUIRE(base + n <= ctx->msm->n_points(), ZKGPU_ERR_INVALID_ARG, "msm: point range outside the loaded SRS");
+        G1Proj sum = n ? ctx->msm->msm(static_cast<const Fr *>(scalars_dev), n, base) : G1Proj::identity();
+        memcpy(out_xyz, sum.x.v, 48);
+        memcpy(out_xyz + 6, sum.y.v, 48);
+        memcpy(out_xyz + 12, sum.z.v, 48);
+    });
+}
+
+int zkgpu_msm_kernels_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(scalars_dev != nullptr && n > 0, ZKGPU_ERR_INVALID_ARG, "msm: null scalars");
+        uint32_t K, c;
+        ctx->msm->msm_device(static_cast<const Fr *>(scalars_dev), n, 0, K, c);
+    });
+}
+
+int zkgpu_g1_sum_to_affine(const uint64_t *xyz, size_t count, uint64_t out_xy[12], uint8_t *out_infinity) {
+    if ((!xyz && count) || !out_xy) return ZKGPU_ERR_INVALID_ARG;
+    G1Proj total = G1Proj::identity();
+    for (size_t i = 0; i < count; i++) {
+        G1Proj p;
+        memcpy(p.x.v, xyz + 18 * i, 48);
+        memcpy(p.y.v, xyz + 18 * i + 6, 48);
+        memcpy(p.z.v, xyz + 18 * i + 12, 48);
+        total = g1_add(total, p);
+    }
+    affine_out(total, out_xy, out_infinity);
+    return ZKGPU_OK;
+}
+
+int zkgpu_commit(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, uint64_t out_xy[12], uint8_t *out_infinity) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(coeffs != nullptr || len == 0, ZKGPU_ERR_INVALID_ARG, "commit: null polynomial");
+        ZK_REQUIRE(ctx->msm->n_points() > 0, ZKGPU_ERR_NOT_LOADED, "commit: no SRS loaded");
+        // Polynomial::degree (plonk/src/fft/polynomial.rs:79-93): index of the highest non-zero coefficient, 0 if none
+        size_t degree = 0;
+        for (size_t i = len; i-- > 0;) {
+            const uint64_t *c = coeffs + 4 * i;
+            if (c[0] | c[1] | c[2] | c[3]) {
+                degree = i;
+                break;
+            }
+        }
+        // check_commit_degree_is_within_bounds (key.rs:108-117); max_degree = powers_of_g.len() - 1
+        ZK_REQUIRE(degree != 0, ZKGPU_ERR_DEGREE_ZERO, "PolynomialDegreeIsZero");
+        ZK_REQUIRE(degree <= ctx->msm->n_points() - 1, ZKGPU_ERR_DEGREE_LARGE, "PolynomialDegreeTooLarge");
+        size_t m = len < ctx->msm->n_points() ? len : ctx->msm->n_points();
+        ctx->stage_b.reserve(m * sizeof(Fr));
+        ZK_HIP(hipMemcpyAsync(ctx->stage_b.p, coeffs, m * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        msm_checked(ctx, ctx->stage_b.as<Fr>(), m, out_xy, out_infinity);
+    });
+}
+
+int zkgpu_g1_compress(const uint64_t xy[12], uint8_t infinity, uint8_t out[48]) {
+    if (!xy || !out) return ZKGPU_ERR_INVALID_ARG;
+    Fq x, y;
+    memcpy(x.v, xy, 48);
+    memcpy(y.v, xy + 6, 48);
+    if (infinity) x = Fq::zero();
+    Fq xc = Fq::from_mont(x), yc = Fq::from_mont(y);
+    for (int i = 0; i < 12; i++) {  // big-endian bytes of the canonical integer (fp.rs:213-228)
+        uint32_t limb = xc.v[11 - i];
+        out[4 * i] = (uint8_t)(limb >> 24);
+        out[4 * i + 1] = (uint8_t)(limb >> 16);
+        out[4 * i + 2] = (uint8_t)(limb >> 8);
+        out[4 * i + 3] = (uint8_t)limb;
+    }
+    out[0] |= 0x80;
+    if (infinity) {
+        out[0] |= 0x40;
+    } else {
+        // lexicographically_largest (fp.rs:264-278): y > (p - 1) / 2
+        static const uint32_t HALF[12] = {0xffffd556u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u,
+                                          0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u};
+        uint64_t borrow = 0;
+        for (int i = 0; i < 12; i++) {
+            uint64_t t = (uint64_t)yc.v[i] - HALF[i] - borrow;
+            borrow = (t >> 32) & 1;
+        }
+        if (!borrow) out[0] |= 0x20;
+    }
+    return ZKGPU_OK;
+}
+
+}  // extern "C"

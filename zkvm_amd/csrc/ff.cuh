@@ -1,0 +1,273 @@
+// Montgomery prime-field arithmetic on 32-bit limbs for gfx950 (and, through the same source, for the
+// host side of the library).  N limbs little-endian; the in-memory image of an element is identical to
+// the reference's 64-bit-limb Montgomery representation (coset-bls12_381/src/scalar.rs:28, fp.rs:23), so
+// buffers cross the C boundary without conversion.  Every result is fully reduced to [0, p), as the
+// reference's are (scalar.rs:524,577; fp.rs:332-348) — results are compared as raw limbs.
+//
+// The multiplier is a product-scanning (column-wise) Montgomery multiplication: each column accumulates
+// a_i*b_j and m_i*p_j partial products into a 96-bit accumulator with v_mad_u64_u32 (+ carry word), which
+// costs one multiply-add and one add-with-carry per partial product and keeps all limbs in VGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FF_HD __host__ __device__ __forceinline__
+
+namespace zk {
+
+// 96-bit column accumulator.
+struct Acc96 {
+    uint64_t lh;  // low 64 bits
+    uint32_t ex;  // bits 64..95
+};
+
+FF_HD void acc_mac(Acc96 &c, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(c.lh), "+v"(c.ex)
+        : "v"(a), "v"(b)
+        : "vcc");
+#else
+    uint64_t p = (uint64_t)a * b;
+    c.lh += p;
+    c.ex += (c.lh < p);
+#endif
+}
+// First product of a column whose accumulator is known to be < 2^33: cannot overflow 64 bits.
+FF_HD void acc_mac_nocarry(Acc96 &c, uint32_t a, uint32_t b) { c.lh += (uint64_t)a * b; }
+
+FF_HD void acc_add32(Acc96 &c, uint32_t v) {
+    uint64_t t = c.lh + v;
+    c.ex += (t < c.lh);
+    c.lh = t;
+}
+FF_HD uint32_t acc_shift(Acc96 &c) {
+    uint32_t lo = (uint32_t)c.lh;
+    c.lh = (c.lh >> 32) | ((uint64_t)c.ex << 32);
+    c.ex = 0;
+    return lo;
+}
+
+// P supplies: static constexpr int N; MOD[N]; R[N] (= one); R2[N]; INV32 (= -p^-1 mod 2^32)
+template <class P>
+struct Fp_ {
+    static constexpr int N = P::N;
+    uint32_t v[N];
+
+    FF_HD static uint32_t mod_limb(int i) { return P::mod(i); }
+
+    FF_HD static Fp_ zero() {
+        Fp_ r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = 0;
+        return r;
+    }
+    FF_HD static Fp_ one() {
+        Fp_ r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = P::one(i);
+        return r;
+    }
+    FF_HD static Fp_ r2() {
+        Fp_ r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = P::r2(i);
+        return r;
+    }
+    FF_HD bool is_zero() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) o |= v[i];
+        return o == 0;
+    }
+    FF_HD bool operator==(const Fp_ &b) const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) o |= v[i] ^ b.v[i];
+        return o == 0;
+    }
+    FF_HD bool operator!=(const Fp_ &b) const { return !(*this == b); }
+
+    // r = a - p if a >= p else a   (a < 2p)
+    FF_HD static Fp_ reduce_once(const Fp_ &a) {
+        Fp_ d;
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint64_t t = (uint64_t)a.v[i] - P::mod(i) - borrow;
+            d.v[i] = (uint32_t)t;
+            borrow = (t >> 32) & 1;
+        }
+        Fp_ r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = borrow ? a.v[i] : d.v[i];
+        return r;
+    }
+
+    FF_HD static Fp_ add(const Fp_ &a, const Fp_ &b) {
+        Fp_ s;
+        uint64_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint64_t t = (uint64_t)a.v[i] + b.v[i] + carry;
+            s.v[i] = (uint32_t)t;
+            carry = t >> 32;
+        }
+        // both moduli leave the top bit(s) of the top limb free, so a + b < 2p never carries out
+        return reduce_once(s);
+    }
+    FF_HD static Fp_ sub(const Fp_ &a, const Fp_ &b) {
+        Fp_ d;
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint64_t t = (uint64_t)a.v[i] - b.v[i] - borrow;
+            d.v[i] = (uint32_t)t;
+            borrow = (t >> 32) & 1;
+        }
+        uint32_t mask = (uint32_t)0 - (uint32_t)borrow;
+        uint64_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint64_t t = (uint64_t)d.v[i] + (P::mod(i) & mask) + carry;
+            d.v[i] = (uint32_t)t;
+            carry = t >> 32;
+        }
+        return d;
+    }
+    FF_HD static Fp_ neg(const Fp_ &a) {
+        Fp_ d;
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint64_t t = (uint64_t)P::mod(i) - a.v[i] - borrow;
+            d.v[i] = (uint32_t)t;
+            borrow = (t >> 32) & 1;
+        }
+        uint32_t mask = a.is_zero() ? 0u : 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < N; i++) d.v[i] &= mask;
+        return d;
+    }
+    FF_HD static Fp_ dbl(const Fp_ &a) { return add(a, a); }
+
+    // Montgomery product a*b*R^-1 mod p, canonical.
+    FF_HD static Fp_ mul(const Fp_ &a, const Fp_ &b) {
+        uint32_t m[N];
+        Fp_ r;
+        Acc96 c;
+        c.lh = 0;
+        c.ex = 0;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) acc_mac(c, a.v[i], b.v[k - i]);
+#pragma unroll
+            for (int i = 0; i < k; i++) acc_mac(c, m[i], P::mod(k - i));
+            m[k] = (uint32_t)c.lh * P::INV32;
+            acc_mac(c, m[k], P::mod(0));
+            (void)acc_shift(c);
+        }
+#pragma unroll
+        for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+            for (int i = k - N + 1; i < N; i++) acc_mac(c, a.v[i], b.v[k - i]);
+#pragma unroll
+            for (int i = k - N + 1; i < N; i++) acc_mac(c, m[i], P::mod(k - i));
+            r.v[k - N] = acc_shift(c);
+        }
+        r.v[N - 1] = (uint32_t)c.lh;
+        return reduce_once(r);
+    }
+    FF_HD static Fp_ sqr(const Fp_ &a) { return mul(a, a); }
+
+    // value * R^-1 : leaves Montgomery form (scalar/coset.rs:242-246 `reduce`)
+    FF_HD static Fp_ from_mont(const Fp_ &a) {
+        Fp_ o = zero();
+        o.v[0] = 1;
+        return mul(a, o);
+    }
+    FF_HD static Fp_ to_mont(const Fp_ &a) { return mul(a, r2()); }
+
+    FF_HD Fp_ operator+(const Fp_ &b) const { return add(*this, b); }
+    FF_HD Fp_ operator-(const Fp_ &b) const { return sub(*this, b); }
+    FF_HD Fp_ operator*(const Fp_ &b) const { return mul(*this, b); }
+    FF_HD Fp_ operator-() const { return neg(*this); }
+
+    // a^e for a multi-limb little-endian exponent (square-and-multiply from the top bit)
+    FF_HD static Fp_ pow(const Fp_ &a, const uint32_t *e, int n_limbs) {
+        Fp_ res = one();
+        for (int l = n_limbs - 1; l >= 0; l--)
+            for (int b = 31; b >= 0; b--) {
+                res = sqr(res);
+                if ((e[l] >> b) & 1) res = mul(res, a);
+            }
+        return res;
+    }
+    FF_HD static Fp_ pow_u64(const Fp_ &a, uint64_t e) {
+        Fp_ res = one();
+        for (int b = 63; b >= 0; b--) {
+            res = sqr(res);
+            if ((e >> b) & 1) res = mul(res, a);
+        }
+        return res;
+    }
+    // a^(p-2); zero maps to zero
+    FF_HD static Fp_ inv(const Fp_ &a) {
+        uint32_t e[N];
+        uint64_t borrow = 2;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint64_t t = (uint64_t)P::mod(i) - borrow;
+            e[i] = (uint32_t)t;
+            borrow = (t >> 32) & 1;
+        }
+        return pow(a, e, N);
+    }
+};
+
+// ---- BLS12-381 scalar field (coset-bls12_381/src/scalar.rs:80-85,156-170) --------------------------------
+struct FrParams {
+    static constexpr int N = 8;
+    static constexpr uint32_t INV32 = 0xffffffffu;
+    FF_HD static uint32_t mod(int i) {
+        constexpr uint32_t M[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
+                                   0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+        return M[i];
+    }
+    FF_HD static uint32_t one(int i) {
+        constexpr uint32_t M[8] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau,
+                                   0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u};
+        return M[i];
+    }
+    FF_HD static uint32_t r2(int i) {
+        constexpr uint32_t M[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
+                                   0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
+        return M[i];
+    }
+};
+// ---- BLS12-381 base field (coset-bls12_381/src/fp.rs:77-104) -----------------------------------------------
+struct FqParams {
+    static constexpr int N = 12;
+    static constexpr uint32_t INV32 = 0xfffcfffdu;
+    FF_HD static uint32_t mod(int i) {
+        constexpr uint32_t M[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                                    0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+        return M[i];
+    }
+    FF_HD static uint32_t one(int i) {
+        constexpr uint32_t M[12] = {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u,
+                                    0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u};
+        return M[i];
+    }
+    FF_HD static uint32_t r2(int i) {
+        constexpr uint32_t M[12] = {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u, 0x4c95b6d5u, 0x8de5476cu,
+                                    0x939d83c0u, 0x67eb88a9u, 0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
+        return M[i];
+    }
+};
+
+typedef Fp_<FrParams> Fr;
+typedef Fp_<FqParams> Fq;
+
+}  // namespace zk

@@ -1,0 +1,442 @@
+// Pippenger bucket MSM for gfx950 with signed window digits and a counting sort of (window, bucket) keys.
+//
+//   1. digits    every scalar leaves Montgomery form and is cut into K signed digits of c bits
+//                (|digit| <= 2^(c-1)); a histogram over the K * 2^(c-1) buckets is built with atomics;
+//   2. scan      exclusive prefix sum of the histogram = bucket start offsets; oversized buckets are cut
+//                into fixed-size tasks so that no thread ever owns more than BIG_BUCKET additions;
+//   3. scatter   point indices (with the digit's sign in bit 31) are written bucket by bucket;
+//   4. accumulate one thread per bucket adds its points with the complete mixed addition; oversized
+//                buckets are summed by whole workgroups (strided partial sums + LDS tree);
+//   5. reduce    sum_b (b+1) * bucket_b per window from segment-wise running sums, then a tree per window;
+//   6. the K window sums return to the host, which runs the Horner chain of doublings and the affine
+//                conversion — a strictly serial chain of ~255 point doublings that would occupy one lane.
+// The reference's unsigned digits, window size and special cases for 0 and 1
+// (multiscalar_mul.rs:150-195) change only the order of group additions; the sum, and so the affine
+// commitment compared by the tests, is the same group element.
+#include "msm.hpp"
+
+namespace zk {
+
+static const uint32_t BIG_BUCKET = 256;   // buckets with more entries are processed by workgroups
+static const uint32_t BIG_CHUNK = 4096;   // entries per workgroup task
+static const uint32_t SCAN_ITEMS = 1024;  // histogram entries scanned per block
+
+struct MsmTask {
+    uint32_t key, start, len, first;  // first = number of tasks of this bucket when this is its first task, else 0
+};
+
+__device__ __forceinline__ Fr gload_fr(const Fr *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ Fq gload_fq(const uint4 *q) {
+    uint4 a = q[0], b = q[1], c = q[2];
+    Fq r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    r.v[8] = c.x; r.v[9] = c.y; r.v[10] = c.z; r.v[11] = c.w;
+    return r;
+}
+__device__ __forceinline__ void gstore_fq(uint4 *q, const Fq &r) {
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+    q[2] = make_uint4(r.v[8], r.v[9], r.v[10], r.v[11]);
+}
+__device__ __forceinline__ G1Affine gload_affine(const G1Affine *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    G1Affine r;
+    r.x = gload_fq(q);
+    r.y = gload_fq(q + 3);
+    return r;
+}
+__device__ __forceinline__ G1Proj gload_proj(const G1Proj *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    G1Proj r;
+    r.x = gload_fq(q);
+    r.y = gload_fq(q + 3);
+    r.z = gload_fq(q + 6);
+    return r;
+}
+__device__ __forceinline__ void gstore_proj(G1Proj *p, const G1Proj &r) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    gstore_fq(q, r.x);
+    gstore_fq(q + 3, r.y);
+    gstore_fq(q + 6, r.z);
+}
+
+// Calls f(window, magnitude, negative) for every non-zero signed digit of the canonical integer s.
+template <class F>
+__device__ __forceinline__ void for_each_digit(Fr s, uint32_t c, uint32_t K, F f) {
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < K; w++) {
+        uint32_t raw = (s.v[0] & mask) + carry;
+#pragma unroll
+        for (int i = 0; i < 7; i++) s.v[i] = (s.v[i] >> c) | (s.v[i + 1] << (32 - c));
+        s.v[7] >>= c;
+        uint32_t mag, neg;
+        if (raw > half) {
+            mag = (1u << c) - raw;
+            neg = 1;
+            carry = 1;
+        } else {
+            mag = raw;
+            neg = 0;
+            carry = 0;
+        }
+        if (mag) f(w, mag, neg);
+    }
+}
+
+__global__ void msm_count_kernel(const Fr *scalars, uint32_t n, uint32_t c, uint32_t K, uint32_t *counts) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = Fr::from_mont(gload_fr(scalars + i));
+    const uint32_t B = 1u << (c - 1);
+    for_each_digit(s, c, K, [&](uint32_t w, uint32_t mag, uint32_t) { atomicAdd(&counts[w * B + mag - 1], 1u); });
+}
+
+__global__ void msm_scatter_kernel(const Fr *scalars, uint32_t n, uint32_t c, uint32_t K, uint32_t *cursor,
+                                   uint32_t *sorted) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = Fr::from_mont(gload_fr(scalars + i));
+    const uint32_t B = 1u << (c - 1);
+    for_each_digit(s, c, K, [&](uint32_t w, uint32_t mag, uint32_t neg) {
+        uint32_t pos = atomicAdd(&cursor[w * B + mag - 1], 1u);
+        sorted[pos] = i | (neg << 31);
+    });
+}
+
+// ---- exclusive scan of the histogram (three small kernels) ------------------------------------------------
+__global__ void __launch_bounds__(256) scan_block_kernel(const uint32_t *counts, uint32_t *offsets, uint32_t *block_sums,
+                                                         uint32_t nb) {
+    __shared__ uint32_t wave_tot[4];
+    const uint32_t tid = threadIdx.x, base = blockIdx.x * SCAN_ITEMS + tid * 4;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v[k] = (base + k < nb) ? counts[base + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t incl = sum;  // inclusive scan of `sum` across the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t up = __shfl_up(incl, d);
+        if ((tid & 63) >= (uint32_t)d) incl += up;
+    }
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0;
+    for (uint32_t w = 0; w < (tid >> 6); w++) wave_base += wave_tot[w];
+    uint32_t run = wave_base + incl - sum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (base + k < nb) offsets[base + k] = run;
+        run += v[k];
+    }
+    if (tid == 255) block_sums[blockIdx.x] = run;
+}
+
+__global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t *block_sums, uint32_t n_blocks) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < n_blocks; start += 1024) {
+        uint32_t i = start + tid;
+        uint32_t v = i < n_blocks ? block_sums[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t up = __shfl_up(incl, d);
+            if ((tid & 63) >= (uint32_t)d) incl += up;
+        }
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t wave_base = 0;
+        for (uint32_t w = 0; w < (tid >> 6); w++) wave_base += wave_tot[w];
+        uint32_t carry = carry_s;
+        if (i < n_blocks) block_sums[i] = carry + wave_base + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wave_base + incl;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) scan_finish_kernel(const uint32_t *counts, uint32_t *offsets, uint32_t *cursor,
+                                                          const uint32_t *block_sums, uint32_t nb, MsmTask *tasks,
+                                                          uint32_t *task_count, uint32_t max_tasks) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    uint32_t off = offsets[i] + block_sums[i / SCAN_ITEMS];
+    offsets[i] = off;
+    cursor[i] = off;
+    uint32_t cnt = counts[i];
+    if (cnt > BIG_BUCKET) {
+        uint32_t nt = (cnt + BIG_CHUNK - 1) / BIG_CHUNK;
+        uint32_t t0 = atomicAdd(task_count, nt);
+        for (uint32_t k = 0; k < nt && t0 + k < max_tasks; k++) {
+            MsmTask t;
+            t.key = i;
+            t.start = off + k * BIG_CHUNK;
+            t.len = (cnt - k * BIG_CHUNK) < BIG_CHUNK ? (cnt - k * BIG_CHUNK) : BIG_CHUNK;
+            t.first = k == 0 ? nt : 0;
+            tasks[t0 + k] = t;
+        }
+    }
+}
+
+// ---- bucket accumulation ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) msm_accumulate_kernel(const G1Affine *points, const uint32_t *sorted,
+                                                             const uint32_t *offsets, const uint32_t *counts,
+                                                             G1Proj *buckets, uint32_t nb) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    uint32_t cnt = counts[b];
+    if (cnt > BIG_BUCKET) return;  // summed by msm_big_* below
+    uint32_t start = offsets[b];
+    G1Proj acc = G1Proj::identity();
+    for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t v = sorted[start + k];
+        G1Affine p = gload_affine(points + (v & 0x7fffffffu));
+        acc = g1_add_mixed(acc, p, (v >> 31) != 0);
+    }
+    gstore_proj(buckets + b, acc);
+}
+
+__device__ __forceinline__ void lds_store_proj(uint32_t *sh, uint32_t slot, const G1Proj &p) {
+    uint32_t *d = sh + slot * 36;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        d[i] = p.x.v[i];
+        d[12 + i] = p.y.v[i];
+        d[24 + i] = p.z.v[i];
+    }
+}
+__device__ __forceinline__ G1Proj lds_load_proj(const uint32_t *sh, uint32_t slot) {
+    const uint32_t *d = sh + slot * 36;
+    G1Proj p;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        p.x.v[i] = d[i];
+        p.y.v[i] = d[12 + i];
+        p.z.v[i] = d[24 + i];
+    }
+    return p;
+}
+// Sums the 256 per-thread points of a workgroup; the total is returned in thread 0.
+__device__ __forceinline__ G1Proj block_tree_sum(uint32_t *sh, G1Proj acc) {
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t stride = 128; stride >= 1; stride >>= 1) {
+        if (tid >= stride && tid < 2 * stride) lds_store_proj(sh, tid - stride, acc);
+        __syncthreads();
+        if (tid < stride) acc = g1_add(acc, lds_load_proj(sh, tid));
+        __syncthreads();
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) msm_big_partial_kernel(const G1Affine *points, const uint32_t *sorted,
+                                                              const MsmTask *tasks, const uint32_t *task_count,
+                                                              uint32_t max_tasks, G1Proj *partials) {
+    __shared__ uint32_t sh[128 * 36];
+    uint32_t n_tasks = *task_count;
+    if (n_tasks > max_tasks) n_tasks = max_tasks;
+    for (uint32_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
+        MsmTask task = tasks[t];
+        G1Proj acc = G1Proj::identity();
+        for (uint32_t k = threadIdx.x; k < task.len; k += 256) {
+            uint32_t v = sorted[task.start + k];
+            G1Affine p = gload_affine(points + (v & 0x7fffffffu));
+            acc = g1_add_mixed(acc, p, (v >> 31) != 0);
+        }
+        acc = block_tree_sum(sh, acc);
+        if (threadIdx.x == 0) gstore_proj(partials + t, acc);
+    }
+}
+
+__global__ void __launch_bounds__(64) msm_big_combine_kernel(const MsmTask *tasks, const uint32_t *task_count,
+                                                             uint32_t max_tasks, const G1Proj *partials, G1Proj *buckets) {
+    uint32_t n_tasks = *task_count;
+    if (n_tasks > max_tasks) n_tasks = max_tasks;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks; t += gridDim.x * blockDim.x) {
+        MsmTask task = tasks[t];
+        if (!task.first) continue;
+        G1Proj acc = gload_proj(partials + t);
+        for (uint32_t k = 1; k < task.first && t + k < n_tasks; k++) acc = g1_add(acc, gload_proj(partials + t + k));
+        gstore_proj(buckets + task.key, acc);
+    }
+}
+
+// ---- bucket reduction -------------------------------------------------------------------------------------
+// One thread per (window, segment of `seg` buckets): sum_r (seg_base + r + 1) * bucket[seg_base + r].
+__global__ void __launch_bounds__(256) msm_segment_kernel(const G1Proj *buckets, uint32_t log_B, uint32_t log_seg,
+                                                          uint32_t n_threads, G1Proj *seg_out) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_threads) return;
+    const uint32_t segs_per_window_log = log_B - log_seg;
+    const uint32_t w = gid >> segs_per_window_log, g = gid & ((1u << segs_per_window_log) - 1u);
+    const uint32_t seg = 1u << log_seg;
+    const G1Proj *bp = buckets + ((size_t)w << log_B) + ((size_t)g << log_seg);
+    G1Proj run = G1Proj::identity(), acc = G1Proj::identity();
+    for (int r = (int)seg - 1; r >= 0; r--) {
+        run = g1_add(run, gload_proj(bp + r));
+        acc = g1_add(acc, run);
+    }
+    if (g) acc = g1_add(acc, g1_mul_small(run, g << log_seg));
+    gstore_proj(seg_out + gid, acc);
+}
+
+// One workgroup per window: sum of its segment results.
+__global__ void __launch_bounds__(256) msm_window_kernel(const G1Proj *seg_out, uint32_t segs_per_window, G1Proj *window_sums) {
+    __shared__ uint32_t sh[128 * 36];
+    const uint32_t w = blockIdx.x;
+    G1Proj acc = G1Proj::identity();
+    for (uint32_t k = threadIdx.x; k < segs_per_window; k += 256) acc = g1_add(acc, gload_proj(seg_out + (size_t)w * segs_per_window + k));
+    acc = block_tree_sum(sh, acc);
+    if (threadIdx.x == 0) gstore_proj(window_sums + w, acc);
+}
+
+// (0,0)-encode points flagged as infinity
+__global__ void msm_mark_infinity_kernel(G1Affine *points, const uint8_t *inf, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !inf[i]) return;
+    uint4 *q = reinterpret_cast<uint4 *>(points + i);
+#pragma unroll
+    for (int k = 0; k < 6; k++) q[k] = make_uint4(0, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+MsmEngine::~MsmEngine() {
+    DevBuf *all[] = {&points_, &counts_, &offsets_, &cursor_, &sorted_, &buckets_, &block_sums_, &tasks_, &partials_,
+                     &misc_,   &seg_,    &window_sums_};
+    for (DevBuf *b : all) b->release();
+}
+
+size_t MsmEngine::device_bytes() const {
+    return points_.cap + counts_.cap + offsets_.cap + cursor_.cap + sorted_.cap + buckets_.cap + block_sums_.cap +
+           tasks_.cap + partials_.cap + misc_.cap + seg_.cap + window_sums_.cap;
+}
+
+void MsmEngine::load_points(const uint64_t *xy_host, const uint8_t *infinity_host, size_t n) {
+    ZK_REQUIRE(xy_host != nullptr || n == 0, ZKGPU_ERR_INVALID_ARG, "srs_load: null points");
+    ZK_REQUIRE(n < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "srs_load: more than 2^31 - 1 points");
+    points_.reserve(n * sizeof(G1Affine) + 16);
+    if (n) ZK_HIP(hipMemcpyAsync(points_.p, xy_host, n * sizeof(G1Affine), hipMemcpyHostToDevice, stream_));
+    if (infinity_host && n) {
+        bool any = false;
+        for (size_t i = 0; i < n && !any; i++) any = infinity_host[i] != 0;
+        if (any) {
+            misc_.reserve(n);
+            ZK_HIP(hipMemcpyAsync(misc_.p, infinity_host, n, hipMemcpyHostToDevice, stream_));
+            hipLaunchKernelGGL(msm_mark_infinity_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_,
+                               points_.as<G1Affine>(), misc_.as<uint8_t>(), (uint32_t)n);
+            ZK_HIP(hipGetLastError());
+        }
+    }
+    ZK_HIP(hipStreamSynchronize(stream_));
+    n_points_ = n;
+}
+
+void MsmEngine::load_points_device(const void *xy_dev, size_t n) {
+    ZK_REQUIRE(xy_dev != nullptr || n == 0, ZKGPU_ERR_INVALID_ARG, "srs_load: null points");
+    ZK_REQUIRE(n < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "srs_load: more than 2^31 - 1 points");
+    points_.reserve(n * sizeof(G1Affine) + 16);
+    if (n) ZK_HIP(hipMemcpyAsync(points_.p, xy_dev, n * sizeof(G1Affine), hipMemcpyDeviceToDevice, stream_));
+    ZK_HIP(hipStreamSynchronize(stream_));
+    n_points_ = n;
+}
+
+// Window width: about log2(n) - 4 bits keeps the ~2^(c-1) * ceil(255/c) buckets at ~n/2 (32 points per bucket
+// for uniform scalars), so accumulation dominates the bucket reduction and every bucket thread has work.
+uint32_t MsmEngine::choose_window(size_t n) {
+    uint32_t lg = 0;
+    while ((1ull << (lg + 1)) <= n) lg++;
+    int c = (int)lg - 4;
+    if (c < 4) c = 4;
+    if (c > 20) c = 20;
+    return (uint32_t)c;
+}
+
+void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_t &n_windows, uint32_t &window_bits) {
+    ZK_REQUIRE(base + n <= n_points_, ZKGPU_ERR_INVALID_ARG, "msm: more scalars than loaded points");
+    ZK_REQUIRE(n >= 1 && n < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "msm: bad length");
+    const uint32_t c = window_override_ ? window_override_ : choose_window(n);
+    const uint32_t K = 255 / c + 1;
+    const uint32_t log_B = c - 1, B = 1u << log_B;
+    const uint32_t nb = K * B;
+    const uint64_t max_entries = (uint64_t)n * K;
+    ZK_REQUIRE(max_entries < (1ull << 32), ZKGPU_ERR_INVALID_ARG, "msm: too many (point, window) pairs for 32-bit offsets");
+    const uint32_t max_tasks = (uint32_t)(max_entries / BIG_BUCKET + 1);
+    const uint32_t n_scan_blocks = ceil_div(nb, SCAN_ITEMS);
+    const uint32_t log_seg = log_B < 3 ? log_B : 3;
+    const uint32_t segs_per_window = 1u << (log_B - log_seg);
+    const uint32_t n_seg_threads = K * segs_per_window;
+
+    counts_.reserve((size_t)nb * 4);
+    offsets_.reserve((size_t)nb * 4);
+    cursor_.reserve((size_t)nb * 4);
+    block_sums_.reserve((size_t)n_scan_blocks * 4 + 4);
+    sorted_.reserve(max_entries * 4);
+    buckets_.reserve((size_t)nb * sizeof(G1Proj));
+    tasks_.reserve((size_t)max_tasks * sizeof(MsmTask) + 16);
+    partials_.reserve((size_t)max_tasks * sizeof(G1Proj));
+    seg_.reserve((size_t)n_seg_threads * sizeof(G1Proj));
+    window_sums_.reserve((size_t)K * sizeof(G1Proj));
+    uint32_t *task_count = reinterpret_cast<uint32_t *>(tasks_.as<char>() + (size_t)max_tasks * sizeof(MsmTask));
+
+    const G1Affine *pts = points_.as<G1Affine>() + base;
+    ZK_HIP(hipMemsetAsync(counts_.p, 0, (size_t)nb * 4, stream_));
+    ZK_HIP(hipMemsetAsync(task_count, 0, 4, stream_));
+    hipLaunchKernelGGL(msm_count_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, scalars_dev, (uint32_t)n, c, K,
+                       counts_.as<uint32_t>());
+    hipLaunchKernelGGL(scan_block_kernel, dim3(n_scan_blocks), dim3(256), 0, stream_, counts_.as<uint32_t>(),
+                       offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream_, block_sums_.as<uint32_t>(), n_scan_blocks);
+    hipLaunchKernelGGL(scan_finish_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, counts_.as<uint32_t>(),
+                       offsets_.as<uint32_t>(), cursor_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb,
+                       tasks_.as<MsmTask>(), task_count, max_tasks);
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, scalars_dev, (uint32_t)n, c, K,
+                       cursor_.as<uint32_t>(), sorted_.as<uint32_t>());
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, pts, sorted_.as<uint32_t>(),
+                       offsets_.as<uint32_t>(), counts_.as<uint32_t>(), buckets_.as<G1Proj>(), nb);
+    const uint32_t big_grid = max_tasks < 2048 ? max_tasks : 2048;
+    hipLaunchKernelGGL(msm_big_partial_kernel, dim3(big_grid), dim3(256), 0, stream_, pts, sorted_.as<uint32_t>(),
+                       tasks_.as<MsmTask>(), task_count, max_tasks, partials_.as<G1Proj>());
+    hipLaunchKernelGGL(msm_big_combine_kernel, dim3(ceil_div(big_grid, 64)), dim3(64), 0, stream_, tasks_.as<MsmTask>(),
+                       task_count, max_tasks, partials_.as<G1Proj>(), buckets_.as<G1Proj>());
+    hipLaunchKernelGGL(msm_segment_kernel, dim3(ceil_div(n_seg_threads, 256)), dim3(256), 0, stream_, buckets_.as<G1Proj>(),
+                       log_B, log_seg, n_seg_threads, seg_.as<G1Proj>());
+    hipLaunchKernelGGL(msm_window_kernel, dim3(K), dim3(256), 0, stream_, seg_.as<G1Proj>(), segs_per_window,
+                       window_sums_.as<G1Proj>());
+    ZK_HIP(hipGetLastError());
+    n_windows = K;
+    window_bits = c;
+}
+
+G1Proj MsmEngine::finish(uint32_t K, uint32_t c) {
+    std::vector<G1Proj> ws(K);
+    ZK_HIP(hipMemcpyAsync(ws.data(), window_sums_.p, (size_t)K * sizeof(G1Proj), hipMemcpyDeviceToHost, stream_));
+    ZK_HIP(hipStreamSynchronize(stream_));
+    // Horner over the windows, highest first (multiscalar_mul.rs:207-219 does the same with its own window size)
+    G1Proj total = G1Proj::identity();
+    for (int w = (int)K - 1; w >= 0; w--) {
+        for (uint32_t k = 0; k < c; k++) total = g1_double(total);
+        total = g1_add(total, ws[w]);
+    }
+    return total;
+}
+
+G1Proj MsmEngine::msm(const Fr *scalars_dev, size_t n, size_t base) {
+    uint32_t K, c;
+    msm_device(scalars_dev, n, base, K, c);
+    return finish(K, c);
+}
+
+}  // namespace zk

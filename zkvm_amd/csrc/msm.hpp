@@ -1,0 +1,44 @@
+// G1 multi-scalar multiplication over a device-resident point table: the MSM behind KZG10
+// CommitKey::commit (plonk/src/commitment_scheme/kzg10/key.rs:119-129 ->
+// coset-bls12_381/src/coset/multiscalar_mul.rs:143-220).
+#pragma once
+#include "common.hpp"
+#include "g1.cuh"
+#include <vector>
+
+namespace zk {
+
+class MsmEngine {
+   public:
+    explicit MsmEngine(hipStream_t s) : stream_(s) {}
+    ~MsmEngine();
+
+    // Uploads n affine points (x | y, 12 x u64 Montgomery limbs each = the first 96 bytes of the reference's
+    // raw point encoding, g1/coset.rs:8-24).  `infinity` may be null.  Replaces any previous table.
+    void load_points(const uint64_t *xy_host, const uint8_t *infinity_host, size_t n);
+    // Same, from a device buffer of n x 96 bytes (copied; infinity = all-zero x and y).
+    void load_points_device(const void *xy_dev, size_t n);
+    size_t n_points() const { return n_points_; }
+
+    // sum_i scalars[i] * points[base + i], i < n.  `scalars_dev` holds n Fr elements in Montgomery form
+    // (device memory).  Synchronous: returns the projective sum after the device work has finished.
+    G1Proj msm(const Fr *scalars_dev, size_t n, size_t base = 0);
+
+    // Device phase only: leaves the per-window sums in an internal buffer and returns their count and window
+    // width; finish() then combines them on the host.  Used to time the kernels without the host tail.
+    void msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_t &n_windows, uint32_t &window_bits);
+    G1Proj finish(uint32_t n_windows, uint32_t window_bits);
+
+    static uint32_t choose_window(size_t n);
+    size_t device_bytes() const;
+    void set_window_override(uint32_t c) { window_override_ = c; }
+
+   private:
+    hipStream_t stream_;
+    DevBuf points_;
+    size_t n_points_ = 0;
+    DevBuf counts_, offsets_, cursor_, sorted_, buckets_, block_sums_, tasks_, partials_, misc_, seg_, window_sums_;
+    uint32_t window_override_ = 0;
+};
+
+}  // namespace zk

@@ -1,0 +1,389 @@
+// Fr NTT for gfx950.
+//
+// Algorithm: one radix-2 decimation-in-frequency network over the whole 2^k-point vector (natural order in,
+// bit-reversed order out), cut into passes by groups of index bits.  A pass keeps a tile of 2^log_r rows x
+// 2^log_t columns in LDS, runs its log_r butterfly stages there, and writes the tile back; the last pass
+// writes each element to its bit-reversed position, so the result is in natural order like the reference's
+// serial_fft (plonk/src/fft/domain.rs:300-340).  Every butterfly takes its twiddle from a per-stage table
+// (entry h-1+i of the table is w_{2h}^i for the stage with half-size h), so a transform costs exactly one
+// field multiplication per butterfly and none for index bookkeeping:
+//   * ifft       = the same network with w^-1 tables, outputs multiplied by 2^-k (domain.rs:150-166) with a
+//                  k-bit Montgomery-style reduction instead of a full multiplication;
+//   * coset_ifft = the network with tables g^(-n/2h) * w_{2h}^-i, which is the transpose of the
+//                  decimation-in-time evaluation network at the points g^-1 w^-i and therefore yields
+//                  g^-j * (iDFT)_j directly (domain.rs:187-196);
+//   * coset_fft  = inputs j < len_in multiplied by g^j while they are loaded (domain.rs:176-185: the powers
+//                  are distributed over the un-padded coefficients), then the forward network.
+// HBM traffic per pass is one read and one write of the vector plus the pass's share of the twiddle table.
+#include "ntt.hpp"
+
+namespace zk {
+
+static Fr fr_from_u64x4(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+    Fr r;
+    const uint64_t w[4] = {a, b, c, d};
+    for (int i = 0; i < 4; i++) {
+        r.v[2 * i] = (uint32_t)w[i];
+        r.v[2 * i + 1] = (uint32_t)(w[i] >> 32);
+    }
+    return r;
+}
+// coset-bls12_381/src/scalar.rs:191-196 and :101-106 (Montgomery form)
+static Fr root_of_unity_2_32() {
+    return fr_from_u64x4(0xb9b58d8c5f0e466aULL, 0x5b1b4c801819d7ecULL, 0x0af53ae352a31e64ULL, 0x5bf3adda19e9b27bULL);
+}
+static Fr coset_generator() {
+    return fr_from_u64x4(0x0000000efffffff1ULL, 0x17e363d300189c0fULL, 0xff9c57876f8457b0ULL, 0x351332208fc5a8c4ULL);
+}
+static const uint32_t TWO_ADACITY = 32;  // scalar.rs:187
+
+Domain Domain::make(uint64_t num_coeffs) {
+    Domain d;
+    uint64_t s = 1;
+    uint32_t lg = 0;
+    while (s < num_coeffs) {
+        s <<= 1;
+        lg++;
+    }
+    ZK_REQUIRE(lg < TWO_ADACITY, ZKGPU_ERR_DOMAIN_SIZE, "InvalidEvalDomainSize: log2(size) must be below 32");
+    d.size = s;
+    d.log_size = lg;
+    d.group_gen = root_of_unity_2_32();
+    for (uint32_t i = lg; i < TWO_ADACITY; i++) d.group_gen = Fr::sqr(d.group_gen);
+    Fr raw = Fr::zero();
+    raw.v[0] = (uint32_t)s;
+    raw.v[1] = (uint32_t)(s >> 32);
+    d.size_as_field_element = Fr::to_mont(raw);
+    d.size_inv = Fr::inv(d.size_as_field_element);
+    d.group_gen_inv = Fr::inv(d.group_gen);
+    d.generator_inv = Fr::inv(coset_generator());
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct NttPassArgs {
+    const Fr *in;
+    Fr *out;
+    const Fr *tw;  // stage tables
+    const Fr *gl;  // g^i, i < 4096      (coset_fft input scaling)
+    const Fr *gh;  // g^(4096 i)
+    uint64_t len_in;
+    uint32_t log_n, b0, log_r, log_t;
+    uint32_t last, coset_in, inv_shift;
+    uint32_t unit_last;  // 1 when the table entry of the h = 1 stage is 1 (plain tables): skip that product
+};
+
+__device__ __forceinline__ Fr lds_get(const uint4 *lo, const uint4 *hi, uint32_t e) {
+    Fr r;
+    uint4 a = lo[e], b = hi[e];
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void lds_put(uint4 *lo, uint4 *hi, uint32_t e, const Fr &r) {
+    lo[e] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    hi[e] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+__device__ __forceinline__ Fr gload(const Fr *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void gstore(Fr *p, const Fr &r) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+// x * 2^-k mod r for 0 <= k < 32: add the multiple of r that clears the low k bits, then shift.
+// r = 1 mod 2^32, so that multiple is (-x) mod 2^k; the quotient is already below r.
+__device__ __forceinline__ Fr fr_div_pow2(const Fr &x, uint32_t k) {
+    if (k == 0) return x;
+    uint32_t m = (0u - x.v[0]) & ((1u << k) - 1u);
+    uint32_t t[9];
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t cur = (uint64_t)m * FrParams::mod(i) + x.v[i] + c;
+        t[i] = (uint32_t)cur;
+        c = cur >> 32;
+    }
+    t[8] = (uint32_t)c;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = (t[i] >> k) | (t[i + 1] << (32 - k));
+    return r;
+}
+
+__global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPassArgs a) {
+    extern __shared__ uint4 lds[];
+    const uint32_t R = 1u << a.log_r, T = 1u << a.log_t, E = R * T;
+    uint4 *lo = lds, *hi = lds + E;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, tile = blockIdx.x;
+    const uint32_t pb = a.log_n - a.log_r - a.b0;  // prefix bits above the row field
+
+    uint32_t base, col0;
+    if (!a.last) {
+        const uint32_t tpp = a.b0 - a.log_t;  // log2(tiles per prefix)
+        const uint32_t prefix = tile >> tpp;
+        col0 = (tile & ((1u << tpp) - 1u)) << a.log_t;
+        base = (prefix << (a.b0 + a.log_r)) | col0;
+    } else {
+        base = tile;  // low part q of the prefix; column u supplies the top log_t prefix bits
+        col0 = 0;
+    }
+
+    // ---- load ----
+    for (uint32_t e = tid; e < E; e += nt) {
+        uint32_t j, t, gi;
+        if (!a.last) {
+            j = e >> a.log_t;
+            t = e & (T - 1);
+            gi = base | (j << a.b0) | t;
+        } else {
+            t = e >> a.log_r;
+            j = e & (R - 1);
+            gi = ((((t << (pb - a.log_t)) | base)) << a.log_r) | j;
+        }
+        Fr x = Fr::zero();
+        if ((uint64_t)gi < a.len_in) {
+            x = gload(a.in + gi);
+            if (a.coset_in) {
+                Fr g = gload(a.gl + (gi & 4095u));
+                if (gi >= 4096u) g = g * gload(a.gh + (gi >> 12));
+                x = x * g;
+            }
+        }
+        lds_put(lo, hi, j * T + t, x);
+    }
+
+    // ---- butterflies ----
+    for (uint32_t hj = R >> 1; hj >= 1; hj >>= 1) {
+        __syncthreads();
+        const uint32_t h = hj << a.b0;  // half-size of this stage in the whole network
+        const uint32_t lhj = 31 - __clz(hj);
+        for (uint32_t bi = tid; bi < (E >> 1); bi += nt) {
+            const uint32_t t = bi & (T - 1);
+            const uint32_t jb = bi >> a.log_t;
+            const uint32_t off = jb & (hj - 1);
+            const uint32_t j = ((jb >> lhj) << (lhj + 1)) | off;
+            const uint32_t e0 = j * T + t, e1 = e0 + hj * T;
+            Fr x = lds_get(lo, hi, e0), y = lds_get(lo, hi, e1);
+            Fr s = x + y, d = x - y;
+            if (h > 1 || !a.unit_last) {
+                const uint32_t widx = (off << a.b0) + (a.last ? 0u : col0 + t);
+                d = d * gload(a.tw + (h - 1) + widx);
+            }
+            lds_put(lo, hi, e0, s);
+            lds_put(lo, hi, e1, d);
+        }
+    }
+    __syncthreads();
+
+    // ---- store ----
+    for (uint32_t e = tid; e < E; e += nt) {
+        if (!a.last) {
+            const uint32_t j = e >> a.log_t, t = e & (T - 1);
+            const uint32_t gi = base | (j << a.b0) | t;
+            gstore(a.out + gi, lds_get(lo, hi, e));
+        } else {
+            // consecutive lanes -> consecutive output positions: the column index is bit-reversed
+            const uint32_t tr = e & (T - 1), j = e >> a.log_t;
+            const uint32_t t = a.log_t ? (__brev(tr) >> (32 - a.log_t)) : 0u;
+            const uint32_t gi = ((((t << (pb - a.log_t)) | base)) << a.log_r) | j;
+            const uint32_t oi = a.log_n ? (__brev(gi) >> (32 - a.log_n)) : 0u;
+            Fr x = lds_get(lo, hi, j * T + t);
+            gstore(a.out + oi, fr_div_pow2(x, a.inv_shift));
+        }
+    }
+}
+
+// out[gid] = c_q * base_q^idx for gid = 2^q - 1 + idx, idx < 2^q ; consts = {base_0, c_0, base_1, c_1, ...}
+__global__ void gen_stage_tables_kernel(Fr *out, uint64_t count, const Fr *consts) {
+    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= count) return;
+    uint32_t q = 63 - __clzll(gid + 1);
+    uint64_t idx = gid + 1 - (1ull << q);
+    Fr b = gload(consts + 2 * q), c = gload(consts + 2 * q + 1);
+    Fr r = c;
+    for (uint32_t bit = 0; bit < q; bit++) {
+        if ((idx >> bit) & 1) r = r * b;
+        b = Fr::sqr(b);
+    }
+    gstore(out + gid, r);
+}
+
+// out[i] = base^i
+__global__ void gen_powers_kernel(Fr *out, uint32_t count, Fr base) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= count) return;
+    Fr r = Fr::one(), b = base;
+    for (uint32_t e = gid; e; e >>= 1) {
+        if (e & 1) r = r * b;
+        b = Fr::sqr(b);
+    }
+    gstore(out + gid, r);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+NttEngine::~NttEngine() {
+    tw_fwd_.release();
+    tw_inv_.release();
+    for (auto &kv : tw_cinv_) kv.second.release();
+    gpow_lo_.release();
+    gpow_hi_.release();
+    work_.release();
+    stage_consts_.release();
+}
+
+size_t NttEngine::device_bytes() const {
+    size_t b = tw_fwd_.cap + tw_inv_.cap + gpow_lo_.cap + gpow_hi_.cap + work_.cap + stage_consts_.cap;
+    for (auto &kv : tw_cinv_) b += kv.second.cap;
+    return b;
+}
+
+static void fill_stage_tables(hipStream_t stream, DevBuf &consts_buf, Fr *table, uint32_t log_n, const Fr &w_n,
+                              const Fr *coset_base /* g^-1 or null */) {
+    // stage q (half-size h = 2^q) uses w_{2h} = w_n^(n/2h) and, for the coset table, c_q = g^(-n/2h)
+    std::vector<Fr> consts(2 * 32, Fr::one());
+    Fr w = w_n;  // w_{2h} for q = log_n - 1
+    Fr c = coset_base ? *coset_base : Fr::one();
+    for (int q = (int)log_n - 1; q >= 0; q--) {
+        consts[2 * q] = w;
+        consts[2 * q + 1] = coset_base ? c : Fr::one();
+        w = Fr::sqr(w);
+        if (coset_base) c = Fr::sqr(c);
+    }
+    consts_buf.reserve(consts.size() * sizeof(Fr));
+    // the previous table generation (if any) reads consts_buf on this stream: order the overwrite after it
+    ZK_HIP(hipStreamSynchronize(stream));
+    ZK_HIP(hipMemcpyAsync(consts_buf.p, consts.data(), consts.size() * sizeof(Fr), hipMemcpyHostToDevice, stream));
+    uint64_t count = (1ull << log_n) - 1;
+    if (count == 0) return;
+    hipLaunchKernelGGL(gen_stage_tables_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, stream, table, count,
+                       consts_buf.as<Fr>());
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(stream));  // consts is a host temporary
+}
+
+void NttEngine::ensure_tables(uint32_t log_n) {
+    if (log_n <= table_log_) return;
+    Domain d = Domain::make(1ull << log_n);
+    size_t bytes = ((1ull << log_n)) * sizeof(Fr);
+    tw_fwd_.reserve(bytes);
+    tw_inv_.reserve(bytes);
+    fill_stage_tables(stream_, stage_consts_, tw_fwd_.as<Fr>(), log_n, d.group_gen, nullptr);
+    fill_stage_tables(stream_, stage_consts_, tw_inv_.as<Fr>(), log_n, d.group_gen_inv, nullptr);
+    table_log_ = log_n;
+}
+
+const Fr *NttEngine::coset_inv_table(uint32_t log_n) {
+    auto it = tw_cinv_.find(log_n);
+    if (it != tw_cinv_.end()) return it->second.as<Fr>();
+    Domain d = Domain::make(1ull << log_n);
+    DevBuf &buf = tw_cinv_[log_n];
+    buf.reserve((1ull << log_n) * sizeof(Fr));
+    // c_q = (g^-1)^(n/2h): for the top stage (h = n/2) that is g^-1 itself
+    fill_stage_tables(stream_, stage_consts_, buf.as<Fr>(), log_n, d.group_gen_inv, &d.generator_inv);
+    return buf.as<Fr>();
+}
+
+void NttEngine::ensure_coset_powers(uint32_t log_n) {
+    uint32_t need = log_n > 12 ? log_n : 12;
+    if (gpow_log_ >= need) return;
+    Fr g = coset_generator();
+    gpow_lo_.reserve(4096 * sizeof(Fr));
+    uint32_t n_hi = 1u << (need - 12);
+    gpow_hi_.reserve((size_t)n_hi * sizeof(Fr));
+    hipLaunchKernelGGL(gen_powers_kernel, dim3(16), dim3(256), 0, stream_, gpow_lo_.as<Fr>(), 4096u, g);
+    Fr g4096 = Fr::pow_u64(g, 4096);
+    hipLaunchKernelGGL(gen_powers_kernel, dim3(ceil_div(n_hi, 256)), dim3(256), 0, stream_, gpow_hi_.as<Fr>(), n_hi, g4096);
+    ZK_HIP(hipGetLastError());
+    gpow_log_ = need;
+}
+
+// Split the k index bits into passes of at most 10 row bits; tiles hold 2^12 elements (128 KiB of LDS).
+std::vector<NttEngine::Pass> NttEngine::plan(uint32_t k) {
+    std::vector<Pass> passes;
+    const uint32_t TILE_LOG = 12, MAX_R = 10;
+    if (k <= TILE_LOG) {
+        passes.push_back(Pass{0, k, 0});
+        return passes;
+    }
+    uint32_t L = (k + MAX_R - 1) / MAX_R;
+    uint32_t hi = k;
+    for (uint32_t i = 0; i < L; i++) {
+        uint32_t r = k / L + (i < k % L ? 1 : 0);
+        uint32_t b0 = hi - r;
+        uint32_t lt = TILE_LOG - r;
+        if (i + 1 < L) {
+            if (lt > b0) lt = b0;
+        } else {
+            uint32_t pb = k - r;  // last pass: columns are prefixes
+            if (lt > pb) lt = pb;
+        }
+        passes.push_back(Pass{b0, r, lt});
+        hi = b0;
+    }
+    return passes;
+}
+
+void NttEngine::transform(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n) {
+    ZK_REQUIRE(log_n < TWO_ADACITY, ZKGPU_ERR_DOMAIN_SIZE, "InvalidEvalDomainSize: log2(size) must be below 32");
+    ZK_REQUIRE(in != nullptr || len_in == 0, ZKGPU_ERR_INVALID_ARG, "ntt: null input");
+    ZK_REQUIRE(out != nullptr, ZKGPU_ERR_INVALID_ARG, "ntt: null output");
+    const uint64_t n = 1ull << log_n;
+    if (len_in > n) len_in = n;  // Vec::resize truncates (domain.rs:146)
+    const bool inverse = (mode == NTT_IFFT || mode == NTT_COSET_IFFT);
+    const Fr *tw;
+    if (mode == NTT_COSET_IFFT) {
+        tw = log_n ? coset_inv_table(log_n) : nullptr;
+    } else {
+        ensure_tables(log_n);
+        tw = inverse ? tw_inv_.as<Fr>() : tw_fwd_.as<Fr>();
+    }
+    if (mode == NTT_COSET_FFT) ensure_coset_powers(log_n);
+
+    std::vector<Pass> passes = plan(log_n);
+    const size_t bytes = n * sizeof(Fr);
+    if (passes.size() > 1) work_.reserve(bytes);
+    const Fr *src = in;
+    for (size_t i = 0; i < passes.size(); i++) {
+        const bool last = (i + 1 == passes.size());
+        NttPassArgs a;
+        a.in = src;
+        a.out = last ? out : work_.as<Fr>();
+        a.tw = tw;
+        a.gl = gpow_lo_.as<Fr>();
+        a.gh = gpow_hi_.as<Fr>();
+        a.len_in = (i == 0) ? (uint64_t)len_in : n;
+        a.log_n = log_n;
+        a.b0 = passes[i].b0;
+        a.log_r = passes[i].log_r;
+        a.log_t = passes[i].log_t;
+        a.last = last ? 1 : 0;
+        a.coset_in = (i == 0 && mode == NTT_COSET_FFT) ? 1 : 0;
+        a.inv_shift = (last && inverse) ? log_n : 0;
+        a.unit_last = (mode == NTT_COSET_IFFT) ? 0 : 1;
+        const uint32_t tile_log = a.log_r + a.log_t;
+        const uint64_t E = 1ull << tile_log;
+        uint32_t threads = (uint32_t)(E / 2);
+        if (threads > 1024) threads = 1024;
+        if (threads < 64) threads = 64;
+        const uint32_t grid = (uint32_t)(n >> tile_log);
+        const size_t lds_bytes = E * sizeof(Fr);
+        if (!lds_attr_set_) {
+            ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            lds_attr_set_ = true;
+        }
+        hipLaunchKernelGGL(ntt_pass_kernel, dim3(grid), dim3(threads), lds_bytes, stream_, a);
+        ZK_HIP(hipGetLastError());
+        src = work_.as<Fr>();
+    }
+}
+
+}  // namespace zk

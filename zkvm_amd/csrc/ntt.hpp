@@ -1,0 +1,53 @@
+// Fr number-theoretic transform over the reference's EvaluationDomain
+// (plonk/src/fft/domain.rs:106-196): fft / ifft / coset_fft / coset_ifft, natural order in and out.
+#pragma once
+#include "common.hpp"
+#include "ff.cuh"
+#include <map>
+#include <vector>
+
+namespace zk {
+
+// Mirror of EvaluationDomain (domain.rs:23-44), computed on the host.
+struct Domain {
+    uint64_t size = 0;
+    uint32_t log_size = 0;
+    Fr size_as_field_element, size_inv, group_gen, group_gen_inv, generator_inv;
+    // domain.rs:106-133; throws ZKGPU_ERR_DOMAIN_SIZE when log2(size) >= 32 (TWO_ADACITY)
+    static Domain make(uint64_t num_coeffs);
+};
+
+enum NttMode { NTT_FFT = 0, NTT_IFFT = 1, NTT_COSET_FFT = 2, NTT_COSET_IFFT = 3 };
+
+class NttEngine {
+   public:
+    explicit NttEngine(hipStream_t s) : stream_(s) {}
+    ~NttEngine();
+    // Transforms `len_in` elements at `in` (zero-padded or truncated to 2^log_n, domain.rs:146) into the
+    // 2^log_n elements at `out`; both are device pointers and may alias.  Asynchronous on the engine's stream.
+    void transform(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n);
+    // Largest transform the twiddle tables currently cover (grown on demand).
+    uint32_t table_log() const { return table_log_; }
+    size_t device_bytes() const;
+
+   private:
+    struct Pass {
+        uint32_t b0, log_r, log_t;
+    };
+    void ensure_tables(uint32_t log_n);
+    const Fr *coset_inv_table(uint32_t log_n);
+    void ensure_coset_powers(uint32_t log_n);
+    static std::vector<Pass> plan(uint32_t log_n);
+
+    hipStream_t stream_;
+    uint32_t table_log_ = 0;
+    DevBuf tw_fwd_, tw_inv_;            // stage tables: entry h-1+i = w_{2h}^{+-i}, h = 1,2,4,...
+    std::map<uint32_t, DevBuf> tw_cinv_;  // per log_n: g^{-n/2h} * w_{2h}^{-i}
+    DevBuf gpow_lo_, gpow_hi_;          // g^i = hi[i >> 12] * lo[i & 4095]
+    uint32_t gpow_log_ = 0;
+    DevBuf work_;                       // ping buffer for multi-pass transforms
+    DevBuf stage_consts_;
+    bool lds_attr_set_ = false;
+};
+
+}  // namespace zk

@@ -1,10 +1,12 @@
 // Pippenger bucket MSM for gfx950 with signed window digits and a counting sort of (window, bucket) keys.
 //
 //   1. digits    every scalar leaves Montgomery form and is cut into K signed digits of c bits
-//                (|digit| <= 2^(c-1)); a histogram over the K * 2^(c-1) buckets is built with atomics;
-//   2. scan      exclusive prefix sum of the histogram = bucket start offsets; oversized buckets are cut
-//                into fixed-size tasks so that no thread ever owns more than BIG_BUCKET additions;
-//   3. scatter   point indices (with the digit's sign in bit 31) are written bucket by bucket;
+//                (|digit| <= 2^(c-1)), one plane of digits per window;
+//   2. sort      counting sort by (window, bucket) with per-workgroup histograms in LDS (no global atomics):
+//                count pass, exclusive scan = bucket start offsets, scatter pass writing point indices (with
+//                the digit's sign in bit 31) bucket by bucket; oversized buckets are cut into fixed-size
+//                tasks so that no thread ever owns more than BIG_BUCKET additions;
+//   3. schedule  buckets are ordered by decreasing size so that the lanes of a wave carry equal work;
 //   4. accumulate one thread per bucket adds its points with the complete mixed addition; oversized
 //                buckets are summed by whole workgroups (strided partial sums + LDS tree);
 //   5. reduce    sum_b (b+1) * bucket_b per window from segment-wise running sums, then a tree per window;
@@ -68,48 +70,82 @@ __device__ __forceinline__ void gstore_proj(G1Proj *p, const G1Proj &r) {
     gstore_fq(q + 6, r.z);
 }
 
-// Calls f(window, magnitude, negative) for every non-zero signed digit of the canonical integer s.
-template <class F>
-__device__ __forceinline__ void for_each_digit(Fr s, uint32_t c, uint32_t K, F f) {
+// dig[w * n + i] = |digit| | sign << 31 of scalar i in window w (0 when the digit is zero)
+__global__ void __launch_bounds__(256) msm_digits_kernel(const Fr *scalars, uint32_t n, uint32_t c, uint32_t K, uint32_t *dig) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = Fr::from_mont(gload_fr(scalars + i));
     const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
     uint32_t carry = 0;
     for (uint32_t w = 0; w < K; w++) {
         uint32_t raw = (s.v[0] & mask) + carry;
 #pragma unroll
-        for (int i = 0; i < 7; i++) s.v[i] = (s.v[i] >> c) | (s.v[i + 1] << (32 - c));
+        for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
         s.v[7] >>= c;
-        uint32_t mag, neg;
+        uint32_t mag = raw, neg = 0;
+        carry = 0;
         if (raw > half) {
             mag = (1u << c) - raw;
             neg = 1;
             carry = 1;
-        } else {
-            mag = raw;
-            neg = 0;
-            carry = 0;
         }
-        if (mag) f(w, mag, neg);
+        dig[(size_t)w * n + i] = mag ? (mag | (neg << 31)) : 0u;
     }
 }
 
-__global__ void msm_count_kernel(const Fr *scalars, uint32_t n, uint32_t c, uint32_t K, uint32_t *counts) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fr s = Fr::from_mont(gload_fr(scalars + i));
-    const uint32_t B = 1u << (c - 1);
-    for_each_digit(s, c, K, [&](uint32_t w, uint32_t mag, uint32_t) { atomicAdd(&counts[w * B + mag - 1], 1u); });
+// Counting sort without global atomics.  Workgroup (s, r, w) owns slice s of the scalars, bucket range r of
+// window w, and a private histogram of that range in LDS.
+//   pass 0 (count):   part[(w * S + s) * B + bucket] = number of slice entries in the bucket
+//   pass 1 (scatter): part[...] holds the first output position for (w, s, bucket); entries are written there
+struct SortGeom {
+    uint32_t n, B, log_range, S, slice;  // slice = ceil(n / S)
+};
+template <int PASS>
+__global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t *dig, SortGeom g, uint32_t *part, uint32_t *sorted) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t range = 1u << g.log_range;
+    const uint32_t s = blockIdx.x, r = blockIdx.y, w = blockIdx.z;
+    uint32_t *mine = part + ((size_t)(w * g.S + s)) * g.B + ((size_t)r << g.log_range);
+    for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) hist[t] = PASS ? mine[t] : 0u;
+    __syncthreads();
+    const uint32_t lo = s * g.slice;
+    uint32_t hi = lo + g.slice;
+    if (hi > g.n) hi = g.n;
+    const uint32_t *d = dig + (size_t)w * g.n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint32_t v = d[i];
+        uint32_t mag = v & 0x7fffffffu;
+        if (!mag) continue;
+        uint32_t b = mag - 1;
+        if ((b >> g.log_range) != r) continue;
+        uint32_t pos = atomicAdd(&hist[b & (range - 1)], 1u);
+        if (PASS) sorted[pos] = i | (v & 0x80000000u);
+    }
+    if (!PASS) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) mine[t] = hist[t];
+    }
 }
 
-__global__ void msm_scatter_kernel(const Fr *scalars, uint32_t n, uint32_t c, uint32_t K, uint32_t *cursor,
-                                   uint32_t *sorted) {
+// counts[w * B + b] = sum over slices
+__global__ void __launch_bounds__(256) msm_totals_kernel(const uint32_t *part, uint32_t nb, uint32_t B, uint32_t S, uint32_t *counts) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fr s = Fr::from_mont(gload_fr(scalars + i));
-    const uint32_t B = 1u << (c - 1);
-    for_each_digit(s, c, K, [&](uint32_t w, uint32_t mag, uint32_t neg) {
-        uint32_t pos = atomicAdd(&cursor[w * B + mag - 1], 1u);
-        sorted[pos] = i | (neg << 31);
-    });
+    if (i >= nb) return;
+    uint32_t w = i / B, b = i - w * B, tot = 0;
+    for (uint32_t s = 0; s < S; s++) tot += part[((size_t)(w * S + s)) * B + b];
+    counts[i] = tot;
+}
+// part[...] <- first output position of every (window, slice, bucket)
+__global__ void __launch_bounds__(256) msm_cursors_kernel(uint32_t *part, const uint32_t *offsets, uint32_t nb, uint32_t B, uint32_t S) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    uint32_t w = i / B, b = i - w * B, run = offsets[i];
+    for (uint32_t s = 0; s < S; s++) {
+        size_t idx = ((size_t)(w * S + s)) * B + b;
+        uint32_t t = part[idx];
+        part[idx] = run;
+        run += t;
+    }
 }
 
 // ---- exclusive scan of the histogram (three small kernels) ------------------------------------------------
@@ -169,14 +205,13 @@ __global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t *block_sums, u
     }
 }
 
-__global__ void __launch_bounds__(256) scan_finish_kernel(const uint32_t *counts, uint32_t *offsets, uint32_t *cursor,
+__global__ void __launch_bounds__(256) scan_finish_kernel(const uint32_t *counts, uint32_t *offsets,
                                                           const uint32_t *block_sums, uint32_t nb, MsmTask *tasks,
                                                           uint32_t *task_count, uint32_t max_tasks) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
     uint32_t off = offsets[i] + block_sums[i / SCAN_ITEMS];
     offsets[i] = off;
-    cursor[i] = off;
     uint32_t cnt = counts[i];
     if (cnt > BIG_BUCKET) {
         uint32_t nt = (cnt + BIG_CHUNK - 1) / BIG_CHUNK;
@@ -192,15 +227,56 @@ __global__ void __launch_bounds__(256) scan_finish_kernel(const uint32_t *counts
     }
 }
 
+// ---- bucket schedule --------------------------------------------------------------------------------------
+// Buckets are visited in order of decreasing size so that the 64 lanes of a wave own buckets of (nearly) equal
+// size.  Size classes: class 0 = BIG_BUCKET entries ... class BIG_BUCKET = empty; oversized buckets are left out
+// (they go through msm_big_*).  Two passes over the counts: class histogram, then placement.
+static const uint32_t N_CLASSES = BIG_BUCKET + 1;
+
+template <int PASS>
+__global__ void __launch_bounds__(1024) msm_schedule_kernel(const uint32_t *counts, uint32_t nb, uint32_t *class_cursor,
+                                                            uint32_t *order) {
+    __shared__ uint32_t hist[N_CLASSES];
+    __shared__ uint32_t base[N_CLASSES];
+    for (uint32_t t = threadIdx.x; t < N_CLASSES; t += blockDim.x) hist[t] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cls = 0xffffffffu, rank = 0;
+    if (i < nb) {
+        uint32_t cnt = counts[i];
+        if (cnt <= BIG_BUCKET) {
+            cls = BIG_BUCKET - cnt;
+            rank = atomicAdd(&hist[cls], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < N_CLASSES; t += blockDim.x)
+        if (hist[t]) base[t] = atomicAdd(&class_cursor[t], hist[t]);
+    if (!PASS) return;
+    __syncthreads();
+    if (cls != 0xffffffffu) order[base[cls] + rank] = i;
+}
+// exclusive scan of the class histogram (in place), total scheduled buckets in class_cursor[N_CLASSES]
+__global__ void msm_schedule_scan_kernel(uint32_t *class_cursor) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t run = 0;
+    for (uint32_t t = 0; t < N_CLASSES; t++) {
+        uint32_t v = class_cursor[t];
+        class_cursor[t] = run;
+        run += v;
+    }
+    class_cursor[N_CLASSES] = run;
+}
+
 // ---- bucket accumulation ----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const G1Affine *points, const uint32_t *sorted,
                                                              const uint32_t *offsets, const uint32_t *counts,
-                                                             G1Proj *buckets, uint32_t nb) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    uint32_t cnt = counts[b];
-    if (cnt > BIG_BUCKET) return;  // summed by msm_big_* below
-    uint32_t start = offsets[b];
+                                                             const uint32_t *order, const uint32_t *n_scheduled,
+                                                             G1Proj *buckets) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= *n_scheduled) return;
+    const uint32_t b = order[gid];
+    const uint32_t cnt = counts[b], start = offsets[b];
     G1Proj acc = G1Proj::identity();
     for (uint32_t k = 0; k < cnt; k++) {
         uint32_t v = sorted[start + k];
@@ -261,16 +337,21 @@ __global__ void __launch_bounds__(256) msm_big_partial_kernel(const G1Affine *po
     }
 }
 
-__global__ void __launch_bounds__(64) msm_big_combine_kernel(const MsmTask *tasks, const uint32_t *task_count,
-                                                             uint32_t max_tasks, const G1Proj *partials, G1Proj *buckets) {
+// One workgroup per oversized bucket: strided sums of its task partials, then the LDS tree.
+__global__ void __launch_bounds__(256) msm_big_combine_kernel(const MsmTask *tasks, const uint32_t *task_count,
+                                                              uint32_t max_tasks, const G1Proj *partials, G1Proj *buckets) {
+    __shared__ uint32_t sh[128 * 36];
     uint32_t n_tasks = *task_count;
     if (n_tasks > max_tasks) n_tasks = max_tasks;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks; t += gridDim.x * blockDim.x) {
+    for (uint32_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
         MsmTask task = tasks[t];
-        if (!task.first) continue;
-        G1Proj acc = gload_proj(partials + t);
-        for (uint32_t k = 1; k < task.first && t + k < n_tasks; k++) acc = g1_add(acc, gload_proj(partials + t + k));
-        gstore_proj(buckets + task.key, acc);
+        if (!task.first) continue;  // uniform across the workgroup
+        uint32_t cnt = task.first;
+        if (t + cnt > n_tasks) cnt = n_tasks - t;
+        G1Proj acc = G1Proj::identity();
+        for (uint32_t k = threadIdx.x; k < cnt; k += 256) acc = g1_add(acc, gload_proj(partials + t + k));
+        acc = block_tree_sum(sh, acc);
+        if (threadIdx.x == 0) gstore_proj(buckets + task.key, acc);
     }
 }
 
@@ -315,13 +396,13 @@ __global__ void msm_mark_infinity_kernel(G1Affine *points, const uint8_t *inf, u
 // ---------------------------------------------------------------------------------------------------------
 MsmEngine::~MsmEngine() {
     DevBuf *all[] = {&points_, &counts_, &offsets_, &cursor_, &sorted_, &buckets_, &block_sums_, &tasks_, &partials_,
-                     &misc_,   &seg_,    &window_sums_};
+                     &misc_,   &seg_,    &window_sums_, &order_, &digits_};
     for (DevBuf *b : all) b->release();
 }
 
 size_t MsmEngine::device_bytes() const {
     return points_.cap + counts_.cap + offsets_.cap + cursor_.cap + sorted_.cap + buckets_.cap + block_sums_.cap +
-           tasks_.cap + partials_.cap + misc_.cap + seg_.cap + window_sums_.cap;
+           tasks_.cap + partials_.cap + misc_.cap + seg_.cap + window_sums_.cap + order_.cap + digits_.cap;
 }
 
 void MsmEngine::load_points(const uint64_t *xy_host, const uint8_t *infinity_host, size_t n) {
@@ -379,9 +460,32 @@ void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_
     const uint32_t segs_per_window = 1u << (log_B - log_seg);
     const uint32_t n_seg_threads = K * segs_per_window;
 
+    // sort geometry: bucket ranges of at most 2^15 (128 KiB of LDS counters), slices so that ~1024 workgroups exist
+    const uint32_t log_range = log_B < 15 ? log_B : 15;
+    const uint32_t n_ranges = 1u << (log_B - log_range);
+    uint32_t S = 1024 / (K * n_ranges);
+    if (S < 1) S = 1;
+    while (S > 1 && n / S < 8192) S >>= 1;  // keep slices long enough to amortise the histogram flush
+    SortGeom geom;
+    geom.n = (uint32_t)n;
+    geom.B = B;
+    geom.log_range = log_range;
+    geom.S = S;
+    geom.slice = (uint32_t)((n + S - 1) / S);
+    const size_t lds_bytes = (size_t)4 << log_range;
+    if (!lds_attr_set_) {
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort_kernel<0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort_kernel<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        lds_attr_set_ = true;
+    }
+
     counts_.reserve((size_t)nb * 4);
     offsets_.reserve((size_t)nb * 4);
-    cursor_.reserve((size_t)nb * 4);
+    cursor_.reserve((size_t)nb * S * 4);                 // per-(window, slice, bucket) counts, then cursors
+    order_.reserve((size_t)nb * 4 + (N_CLASSES + 1) * 4);
+    digits_.reserve(max_entries * 4);
     block_sums_.reserve((size_t)n_scan_blocks * 4 + 4);
     sorted_.reserve(max_entries * 4);
     buckets_.reserve((size_t)nb * sizeof(G1Proj));
@@ -390,27 +494,41 @@ void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_
     seg_.reserve((size_t)n_seg_threads * sizeof(G1Proj));
     window_sums_.reserve((size_t)K * sizeof(G1Proj));
     uint32_t *task_count = reinterpret_cast<uint32_t *>(tasks_.as<char>() + (size_t)max_tasks * sizeof(MsmTask));
+    uint32_t *order = order_.as<uint32_t>();
+    uint32_t *class_cursor = order + nb;
 
     const G1Affine *pts = points_.as<G1Affine>() + base;
-    ZK_HIP(hipMemsetAsync(counts_.p, 0, (size_t)nb * 4, stream_));
     ZK_HIP(hipMemsetAsync(task_count, 0, 4, stream_));
-    hipLaunchKernelGGL(msm_count_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, scalars_dev, (uint32_t)n, c, K,
+    ZK_HIP(hipMemsetAsync(class_cursor, 0, (N_CLASSES + 1) * 4, stream_));
+    hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, scalars_dev, (uint32_t)n, c, K,
+                       digits_.as<uint32_t>());
+    const dim3 sort_grid(S, n_ranges, K);
+    hipLaunchKernelGGL(msm_sort_kernel<0>, sort_grid, dim3(1024), lds_bytes, stream_, digits_.as<uint32_t>(), geom,
+                       cursor_.as<uint32_t>(), sorted_.as<uint32_t>());
+    hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, cursor_.as<uint32_t>(), nb, B, S,
                        counts_.as<uint32_t>());
     hipLaunchKernelGGL(scan_block_kernel, dim3(n_scan_blocks), dim3(256), 0, stream_, counts_.as<uint32_t>(),
                        offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream_, block_sums_.as<uint32_t>(), n_scan_blocks);
     hipLaunchKernelGGL(scan_finish_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, counts_.as<uint32_t>(),
-                       offsets_.as<uint32_t>(), cursor_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb,
-                       tasks_.as<MsmTask>(), task_count, max_tasks);
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, scalars_dev, (uint32_t)n, c, K,
+                       offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb, tasks_.as<MsmTask>(), task_count, max_tasks);
+    hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, cursor_.as<uint32_t>(),
+                       offsets_.as<uint32_t>(), nb, B, S);
+    hipLaunchKernelGGL(msm_sort_kernel<1>, sort_grid, dim3(1024), lds_bytes, stream_, digits_.as<uint32_t>(), geom,
                        cursor_.as<uint32_t>(), sorted_.as<uint32_t>());
+    // schedule: class histogram, scan, placement
+    hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(nb, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), nb,
+                       class_cursor, order);
+    hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(1), dim3(64), 0, stream_, class_cursor);
+    hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(nb, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), nb,
+                       class_cursor, order);
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, pts, sorted_.as<uint32_t>(),
-                       offsets_.as<uint32_t>(), counts_.as<uint32_t>(), buckets_.as<G1Proj>(), nb);
+                       offsets_.as<uint32_t>(), counts_.as<uint32_t>(), order, class_cursor + N_CLASSES, buckets_.as<G1Proj>());
     const uint32_t big_grid = max_tasks < 2048 ? max_tasks : 2048;
     hipLaunchKernelGGL(msm_big_partial_kernel, dim3(big_grid), dim3(256), 0, stream_, pts, sorted_.as<uint32_t>(),
                        tasks_.as<MsmTask>(), task_count, max_tasks, partials_.as<G1Proj>());
-    hipLaunchKernelGGL(msm_big_combine_kernel, dim3(ceil_div(big_grid, 64)), dim3(64), 0, stream_, tasks_.as<MsmTask>(),
-                       task_count, max_tasks, partials_.as<G1Proj>(), buckets_.as<G1Proj>());
+    hipLaunchKernelGGL(msm_big_combine_kernel, dim3(big_grid), dim3(256), 0, stream_, tasks_.as<MsmTask>(), task_count,
+                       max_tasks, partials_.as<G1Proj>(), buckets_.as<G1Proj>());
     hipLaunchKernelGGL(msm_segment_kernel, dim3(ceil_div(n_seg_threads, 256)), dim3(256), 0, stream_, buckets_.as<G1Proj>(),
                        log_B, log_seg, n_seg_threads, seg_.as<G1Proj>());
     hipLaunchKernelGGL(msm_window_kernel, dim3(K), dim3(256), 0, stream_, seg_.as<G1Proj>(), segs_per_window,

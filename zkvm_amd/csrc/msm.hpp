@@ -38,7 +38,9 @@ class MsmEngine {
     DevBuf points_;
     size_t n_points_ = 0;
     DevBuf counts_, offsets_, cursor_, sorted_, buckets_, block_sums_, tasks_, partials_, misc_, seg_, window_sums_;
+    DevBuf order_, digits_;
     uint32_t window_override_ = 0;
+    bool lds_attr_set_ = false;
 };
 
 }  // namespace zk

@@ -119,6 +119,57 @@ int zkgpu_commit(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, uint64_t ou
  * transcript absorbs.  Host-only. */
 int zkgpu_g1_compress(const uint64_t xy[12], uint8_t infinity, uint8_t out[48]);
 
+/* ---- ProverKey / Prover ---------------------------------------------------------------------------------- */
+/* Order of the 15 selector / sigma vectors in every array below:
+ *   q_m q_l q_r q_o q_f q_c q_arith q_range q_logic q_fixed_group_add q_variable_group_add s_sigma_1..4 */
+#define ZKGPU_N_SELECTORS 15
+
+/* Compiler::preprocess (plonk/src/compiler.rs:78-390) on the GPU: `selector_evals` holds 15 x n gate-wise
+ * values (n a power of two; the four sigma rows are the values produced by build_permutation_lagrange_mapping,
+ * plonk/src/composer/permutation.rs:111-141).  Builds the resident ProverKey (15 coefficient vectors, their 8n
+ * coset evaluations, X and L_1 on the coset, 1/Z_H) and the 15 commitments that seed the transcript
+ * (plonk/src/proof_system/widget.rs:199-228).  The SRS must be loaded first.  `constraints` is the gate
+ * count the reference passes to Transcript::base and EvaluationDomain::new; `pi_indexes` are the gate indexes of
+ * the public inputs in ascending order (composer.rs:985-992). */
+int zkgpu_prover_key_load(zkgpu_ctx *ctx, uint32_t n, uint64_t constraints, const uint64_t *selector_evals,
+                          const char *label, size_t label_len, const uint64_t *pi_indexes, size_t n_pi);
+/* The 15 commitments of the loaded key (x | y, 12 limbs each) and their infinity flags. */
+int zkgpu_prover_key_commitments(zkgpu_ctx *ctx, uint64_t *out_xy, uint8_t *out_infinity);
+/* Copies of key members for inspection: coefficient vector `which` (n elements), and the 8n coset evaluations
+ * `which` in 0..14 (selectors), 15 (linear_evaluations) or 16 (L_1, unscaled). */
+int zkgpu_prover_key_poly(zkgpu_ctx *ctx, int which, uint64_t *out);
+int zkgpu_prover_key_eval8n(zkgpu_ctx *ctx, int which, uint64_t *out);
+
+/* build_quotient_polynomial (plonk/src/proof_system/quotient_poly.rs:15-100).  `polys` packs the coefficient
+ * vectors z, a, b, c, d, pi back to back with lens[6]; challenges7 = alpha beta gamma range logic fixed_base
+ * var_base.  t_out receives 8n coefficients of which *t_len remain after dropping leading zeros. */
+int zkgpu_quotient(zkgpu_ctx *ctx, const uint64_t *polys, const size_t lens[6], const uint64_t *challenges7,
+                   uint64_t *t_out, size_t *t_len);
+/* Permutation::compute_permutation_vec (plonk/src/composer/permutation.rs:181-245): wires and sigma_evals hold
+ * 4 x n values each (sigma_evals = the FFT of the sigma polynomials, i.e. the sigma values). */
+int zkgpu_perm_z(zkgpu_ctx *ctx, uint32_t n, const uint64_t *wires, const uint64_t *sigma_evals, const uint64_t beta[4],
+                 const uint64_t gamma[4], uint64_t *z_out);
+/* Polynomial::evaluate (plonk/src/fft/polynomial.rs:105-119) and Polynomial::ruffini (:343-357; out receives
+ * len - 1 coefficients). */
+int zkgpu_poly_eval(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, const uint64_t x[4], uint64_t out[4]);
+int zkgpu_poly_ruffini(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, const uint64_t root[4], uint64_t *out);
+
+/* Prover::prove (plonk/src/compiler/prover.rs:210-509) for the loaded key.  `wires` holds the 4 x n gate-wise
+ * values a, b, c, d; `public_inputs` the n_pi public input values in index order; `blinders14` the 14 scalars
+ * the reference draws from its RNG, in draw order a(2) b(2) c(2) d(2) z(3) b12 b13 b14.  Outputs: the 11
+ * commitments in the order of Proof (a b c d z t_low t_mid t_high t_fourth w_z w_zw), the 15 evaluations in
+ * ProofEvaluations field order, the ten challenges (beta gamma alpha range logic fixed var z v v_w) and,
+ * when timings8 is not NULL, milliseconds per phase.  ZKGPU_ERR_DEGREE_* mirror the reference's commit errors;
+ * ZKGPU_ERR_QUOTIENT_SHAPE is returned where the reference would panic on a too-short quotient. */
+int zkgpu_prove(zkgpu_ctx *ctx, const uint64_t *wires, const uint64_t *public_inputs, size_t n_pi,
+                const uint64_t *blinders14, uint64_t *out_comms_xy, uint8_t *out_comms_infinity, uint64_t *out_evals15,
+                uint64_t *out_challenges10, float *timings8);
+
+/* Transcript::new(label); append_message(msg_label, msg); challenge_bytes(ch_label, out): conformance hook for the
+ * host-side Merlin implementation the prover's transcript uses (plonk/src/transcript.rs). Host-only. */
+int zkgpu_transcript_challenge(const char *label, const char *msg_label, const uint8_t *msg, size_t msg_len,
+                               const char *ch_label, uint8_t *out, size_t out_len);
+
 #ifdef __cplusplus
 }
 #endif

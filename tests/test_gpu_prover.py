@@ -1,0 +1,187 @@
+"""GPU parity of the PLONK prover path through the C boundary: permutation accumulator, polynomial evaluation and
+Ruffini division, key preprocessing, quotient polynomial and the whole of Prover::prove, bit for bit against the
+CPU oracle on the same seeded circuits (arithmetic gates, copy constraints, one public input)."""
+import numpy as np
+import pytest
+
+import model as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import zkvm_amd
+    c = zkvm_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def srs(orc):
+    tau = M.random_fr_mont(1, seed=77)[0]
+    g = orc.g1_generator()
+    xy, inf = orc.srs_powers(g, tau, (1 << 12) + 7)
+    assert not inf.any()
+    return xy
+
+
+def _circuit(orc, n, seed=5, constraints=None):
+    from zkvm_amd import circuits
+    c = circuits.arithmetic_circuit(n, constraints=constraints, seed=seed)
+    c["selectors"][11:15] = np.stack([orc.sigma_to_lagrange(c["sigma_map"][k]) for k in range(4)])
+    return c
+
+
+def test_fill_sigma_rows_matches_oracle(ctx, orc):
+    from zkvm_amd import circuits
+    c = circuits.arithmetic_circuit(64, seed=3)
+    want = np.stack([orc.sigma_to_lagrange(c["sigma_map"][k]) for k in range(4)])
+    circuits.fill_sigma_rows(c, ctx)
+    assert np.array_equal(c["selectors"][11:15], want)
+
+
+@pytest.mark.parametrize("log_n", [2, 5, 10, 13, 15])
+def test_perm_z(ctx, orc, log_n):
+    from zkvm_amd import api
+    n = 1 << log_n
+    wires = M.random_fr_mont(4 * n, seed=log_n).reshape(4, n, 4)
+    sig = M.random_fr_mont(4 * n, seed=100 + log_n).reshape(4, n, 4)
+    beta, gamma = M.random_fr_mont(2, seed=200 + log_n)
+    sigma_polys = [orc.fft("ifft", sig[k]) for k in range(4)]
+    want = orc.permutation_vec(wires, sigma_polys, beta, gamma)
+    got = api.perm_z(ctx, wires, sig, beta, gamma)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("length", [0, 1, 2, 63, 64, 65, 1000, 4096, (1 << 14) + 3, (1 << 17) + 11])
+def test_poly_eval(ctx, orc, length):
+    from zkvm_amd import api
+    c = M.random_fr_mont(length, seed=length) if length else np.zeros((0, 4), np.uint64)
+    x = M.random_fr_mont(1, seed=9)[0]
+    assert np.array_equal(api.poly_eval(ctx, c, x), orc.poly_evaluate(c, x))
+    zero = np.zeros(4, np.uint64)
+    assert np.array_equal(api.poly_eval(ctx, c, zero), orc.poly_evaluate(c, zero))
+
+
+@pytest.mark.parametrize("length", [1, 2, 3, 100, 1024, (1 << 13) + 5, (1 << 16) + 9])
+def test_poly_ruffini(ctx, orc, length):
+    from zkvm_amd import api
+    c = M.random_fr_mont(length, seed=length + 1)
+    root = M.random_fr_mont(1, seed=10)[0]
+    want = orc.poly_ruffini(c, root)
+    got = api.poly_ruffini(ctx, c, root)
+    assert got.shape[0] == length - 1
+    assert np.array_equal(got[:want.shape[0]], want)
+    assert not got[want.shape[0]:].any()
+    zero = np.zeros(4, np.uint64)
+    want = orc.poly_ruffini(c, zero)
+    got = api.poly_ruffini(ctx, c, zero)
+    assert np.array_equal(got[:want.shape[0]], want) and not got[want.shape[0]:].any()
+
+
+def _provers(ctx, orc, srs, c, label=b"parity"):
+    from zkvm_amd import api
+    n = c["n"]
+    ctx.srs_load(srs[:n + 7])
+    gp = api.Prover(ctx, n, c["constraints"], c["selectors"].reshape(-1, 4), label, c["pi_indexes"])
+    op = orc.Prover(n, c["constraints"], c["selectors"], srs[:n + 7], label, c["pi_indexes"], threads=4)
+    assert op.preprocess_rc == 0
+    return gp, op
+
+
+@pytest.mark.parametrize("log_n", [4, 10])
+def test_key_preprocess(ctx, orc, srs, log_n):
+    n = 1 << log_n
+    c = _circuit(orc, n)
+    gp, op = _provers(ctx, orc, srs, c)
+    for k in range(15):
+        want = op.poly(k)
+        got = gp.key_poly(k)
+        assert np.array_equal(got[:want.shape[0]], want), k
+        assert not got[want.shape[0]:].any(), k
+    for k in range(16):
+        assert np.array_equal(gp.key_eval8n(k), op.eval8n(k)), k
+    # member 16: the first Lagrange polynomial on the 8n coset (compute_first_lagrange_poly_scaled with scale 1,
+    # quotient_poly.rs:222-231)
+    e0 = np.zeros((n, 4), np.uint64)
+    e0[0] = M.fr_to_mont(1)
+    l1 = orc.fft("coset_fft", orc.fft("ifft", e0), 8 * n)
+    assert np.array_equal(gp.key_eval8n(16), l1)
+    gxy, ginf = gp.selector_commitments()
+    oxy, oinf = op.selector_comms()
+    assert np.array_equal(ginf, oinf)
+    for k in range(15):
+        if not oinf[k]:
+            assert np.array_equal(gxy[k], oxy[k]), k
+
+
+@pytest.mark.parametrize("log_n", [4, 10])
+def test_quotient(ctx, orc, srs, log_n):
+    n = 1 << log_n
+    c = _circuit(orc, n, seed=8)
+    gp, op = _provers(ctx, orc, srs, c)
+    ch = M.random_fr_mont(7, seed=31)
+    wires = c["wires"]
+    # blinded wire polynomials (n + 2 coefficients) exercise the padded coset FFTs
+    polys = []
+    bl = M.random_fr_mont(8, seed=32)
+    for k in range(4):
+        p = np.zeros((n + 2, 4), np.uint64)
+        p[:n] = orc.fft("ifft", wires[k])
+        polys.append(p)
+    sigma_polys = [op.poly(11 + k) for k in range(4)]
+    zvec = orc.permutation_vec(wires, sigma_polys, ch[1], ch[2])
+    z = orc.fft("ifft", zvec)
+    dense_pi = np.zeros((n, 4), np.uint64)
+    dense_pi[0] = c["public_inputs"][0]
+    pi = orc.fft("ifft", dense_pi)
+    want = op.quotient(z, *polys, pi, ch)
+    got = gp.quotient(z, *polys, pi, ch)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+    assert want.shape[0] <= 4 * n   # the circuit is satisfied: the division is exact (degree 4n - 5)
+
+
+@pytest.mark.parametrize("log_n,seed", [(3, 1), (4, 2), (7, 3), (10, 4), (12, 5)])
+def test_prove(ctx, orc, srs, log_n, seed):
+    from zkvm_amd import api, circuits
+    n = 1 << log_n
+    c = _circuit(orc, n, seed=seed)
+    gp, op = _provers(ctx, orc, srs, c)
+    bl = circuits.random_blinders(seed)
+    want = op.prove(c["wires"], c["public_inputs"], bl)
+    assert want["rc"] == 0
+    got = gp.prove(c["wires"].reshape(-1, 4), c["public_inputs"], bl, timings=True)
+    assert np.array_equal(got["challenges"], want["challenges"])
+    assert np.array_equal(got["evals"], want["evals"])
+    assert np.array_equal(got["comms_inf"], want["comms_inf"])
+    for k in range(11):
+        assert np.array_equal(got["comms"][k], want["comms"][k]), api.COMMITMENT_NAMES[k]
+    assert got["timings_ms"]["total"] > 0
+
+
+def test_prove_twice_same_key(ctx, orc, srs):
+    """The per-proof buffers are reused: a second proof with other blinders on the same key stays exact."""
+    from zkvm_amd import circuits
+    c = _circuit(orc, 256, seed=12)
+    gp, op = _provers(ctx, orc, srs, c)
+    for s in (1, 2):
+        bl = circuits.random_blinders(s)
+        want = op.prove(c["wires"], c["public_inputs"], bl)
+        got = gp.prove(c["wires"].reshape(-1, 4), c["public_inputs"], bl)
+        assert np.array_equal(got["comms"], want["comms"]) and np.array_equal(got["evals"], want["evals"])
+
+
+def test_prove_unsatisfied_circuit(ctx, orc, srs):
+    """A witness violating a gate leaves a quotient of 8n coefficients; its fourth slice exceeds the SRS and the
+    reference's commit returns PolynomialDegreeTooLarge (kzg10/key.rs:91-105)."""
+    from zkvm_amd import api, circuits
+    c = _circuit(orc, 64, seed=6)
+    gp, op = _provers(ctx, orc, srs, c)
+    w = c["wires"].copy()
+    w[2, 5, 0] ^= np.uint64(1)
+    bl = circuits.random_blinders(1)
+    assert op.prove(w, c["public_inputs"], bl)["rc"] == 2
+    with pytest.raises(api.PolynomialDegreeTooLarge):
+        gp.prove(w.reshape(-1, 4), c["public_inputs"], bl)

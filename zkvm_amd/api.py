@@ -210,3 +210,118 @@ class CommitKey:
     def commit(self, polynomial):
         """-> (xy, infinity).  Raises PolynomialDegreeIsZero / PolynomialDegreeTooLarge like the reference."""
         return self.ctx.commit(polynomial)
+
+
+N_SELECTORS = 15
+SELECTOR_NAMES = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic", "q_fixed_group_add",
+                  "q_variable_group_add", "s_sigma_1", "s_sigma_2", "s_sigma_3", "s_sigma_4"]
+COMMITMENT_NAMES = ["a_comm", "b_comm", "c_comm", "d_comm", "z_comm", "t_low_comm", "t_mid_comm", "t_high_comm",
+                    "t_fourth_comm", "w_z_chall_comm", "w_z_chall_w_comm"]
+EVALUATION_NAMES = ["a_eval", "b_eval", "c_eval", "d_eval", "a_w_eval", "b_w_eval", "d_w_eval", "q_arith_eval", "q_c_eval",
+                    "q_l_eval", "q_r_eval", "s_sigma_1_eval", "s_sigma_2_eval", "s_sigma_3_eval", "z_eval"]
+PHASE_NAMES = ["wire_commits", "permutation", "quotient", "quotient_commits", "evaluations", "linearization", "openings",
+               "total"]
+
+
+class QuotientTooShort(ValueError):
+    """The quotient has fewer than 3n + 1 coefficients: the reference's prove() panics on its slicing here."""
+
+
+_ERR_CLASSES[-9] = QuotientTooShort
+
+
+class Prover:
+    """Compiler::preprocess + Prover::prove of the reference (plonk/src/compiler.rs:78-390,
+    plonk/src/compiler/prover.rs:210-509) with the ProverKey resident in HBM.  The SRS must be loaded into `ctx`
+    first (CommitKey / Context.srs_load)."""
+
+    def __init__(self, ctx, n, constraints, selector_evals, label=b"zkgpu", pi_indexes=()):
+        sel = _np_u64(selector_evals, 4)
+        assert sel.shape[0] == N_SELECTORS * n
+        idx = np.ascontiguousarray(list(pi_indexes), dtype=np.uint64)
+        self.ctx, self.n, self.constraints = ctx, int(n), int(constraints)
+        ctx._check(ctx._lib.zkgpu_prover_key_load(ctx._h, int(n), int(constraints), sel.ctypes.data, bytes(label),
+                                                  len(label), idx.ctypes.data if idx.size else None, idx.size))
+
+    def selector_commitments(self):
+        xy = np.zeros((N_SELECTORS, 12), dtype=np.uint64)
+        inf = np.zeros(N_SELECTORS, dtype=np.uint8)
+        self.ctx._check(self.ctx._lib.zkgpu_prover_key_commitments(self.ctx._h, xy.ctypes.data, inf.ctypes.data))
+        return xy, inf
+
+    def key_poly(self, which):
+        out = np.zeros((self.n, 4), dtype=np.uint64)
+        self.ctx._check(self.ctx._lib.zkgpu_prover_key_poly(self.ctx._h, which, out.ctypes.data))
+        return out
+
+    def key_eval8n(self, which):
+        out = np.zeros((8 * self.n, 4), dtype=np.uint64)
+        self.ctx._check(self.ctx._lib.zkgpu_prover_key_eval8n(self.ctx._h, which, out.ctypes.data))
+        return out
+
+    def quotient(self, z, a, b, c, d, pi, challenges7):
+        """build_quotient_polynomial -> coefficient array with leading zeros dropped."""
+        polys = [_np_u64(p, 4) for p in (z, a, b, c, d, pi)]
+        lens = (C.c_size_t * 6)(*[p.shape[0] for p in polys])
+        packed = np.ascontiguousarray(np.concatenate(polys, axis=0))
+        ch = _np_u64(challenges7, 4)
+        out = np.zeros((8 * self.n, 4), dtype=np.uint64)
+        t_len = C.c_size_t(0)
+        self.ctx._check(self.ctx._lib.zkgpu_quotient(self.ctx._h, packed.ctypes.data, lens, ch.ctypes.data,
+                                                     out.ctypes.data, C.byref(t_len)))
+        return out[:t_len.value].copy()
+
+    def prove(self, wires, public_inputs, blinders14, timings=False):
+        w = _np_u64(wires, 4)
+        assert w.shape[0] == 4 * self.n
+        pi = _np_u64(public_inputs, 4)
+        bl = _np_u64(blinders14, 4)
+        assert bl.shape[0] == 14
+        comms = np.zeros((11, 12), dtype=np.uint64)
+        inf = np.zeros(11, dtype=np.uint8)
+        evals = np.zeros((15, 4), dtype=np.uint64)
+        chal = np.zeros((10, 4), dtype=np.uint64)
+        tm = (C.c_float * 8)()
+        self.ctx._check(self.ctx._lib.zkgpu_prove(self.ctx._h, w.ctypes.data, pi.ctypes.data if pi.size else None,
+                                                  pi.shape[0], bl.ctypes.data, comms.ctypes.data, inf.ctypes.data,
+                                                  evals.ctypes.data, chal.ctypes.data, tm if timings else None))
+        out = dict(comms=comms, comms_inf=inf, evals=evals, challenges=chal)
+        if timings:
+            out["timings_ms"] = dict(zip(PHASE_NAMES, [float(x) for x in tm]))
+        return out
+
+
+def perm_z(ctx, wires, sigma_evals, beta, gamma):
+    w = _np_u64(wires, 4)
+    s = _np_u64(sigma_evals, 4)
+    n = w.shape[0] // 4
+    out = np.zeros((n, 4), dtype=np.uint64)
+    ctx._check(ctx._lib.zkgpu_perm_z(ctx._h, n, w.ctypes.data, s.ctypes.data, _np_u64(beta, 4).ctypes.data,
+                                     _np_u64(gamma, 4).ctypes.data, out.ctypes.data))
+    return out
+
+
+def poly_eval(ctx, coeffs, x):
+    c = _np_u64(coeffs, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    ctx._check(ctx._lib.zkgpu_poly_eval(ctx._h, c.ctypes.data if c.size else None, c.shape[0], _np_u64(x, 4).ctypes.data,
+                                        out.ctypes.data))
+    return out
+
+
+def poly_ruffini(ctx, coeffs, root):
+    c = _np_u64(coeffs, 4)
+    out = np.zeros((max(c.shape[0] - 1, 0), 4), dtype=np.uint64)
+    ctx._check(ctx._lib.zkgpu_poly_ruffini(ctx._h, c.ctypes.data if c.size else None, c.shape[0],
+                                           _np_u64(root, 4).ctypes.data, out.ctypes.data if out.size else None))
+    return out
+
+
+def transcript_challenge(label, msg_label, msg, ch_label, n):
+    out = np.zeros(n, dtype=np.uint8)
+    m = np.frombuffer(bytes(msg), dtype=np.uint8).copy()
+    rc = _lib.lib().zkgpu_transcript_challenge(bytes(label), bytes(msg_label), m.ctypes.data if m.size else None, m.size,
+                                               bytes(ch_label), out.ctypes.data, n)
+    if rc != 0:
+        raise ZkGpuError(rc, "transcript_challenge")
+    return bytes(out)

@@ -3,6 +3,9 @@
 #include "common.hpp"
 #include "msm.hpp"
 #include "ntt.hpp"
+#include "poly.hpp"
+#include "prover.hpp"
+#include "transcript.hpp"
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -14,6 +17,8 @@ struct zkgpu_ctx {
     hipStream_t stream = nullptr;
     std::unique_ptr<NttEngine> ntt;
     std::unique_ptr<MsmEngine> msm;
+    std::unique_ptr<PolyEngine> poly;
+    std::unique_ptr<Prover> prover;
     DevBuf stage_a, stage_b;  // staging for the host-pointer entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string last_error;
@@ -80,6 +85,8 @@ int zkgpu_init(zkgpu_ctx **out, int device_id) {
         ZK_HIP(hipEventCreate(&ctx->ev1));
         ctx->ntt.reset(new NttEngine(ctx->stream));
         ctx->msm.reset(new MsmEngine(ctx->stream));
+        ctx->poly.reset(new PolyEngine(ctx->stream));
+        ctx->prover.reset(new Prover(ctx->stream, *ctx->ntt, *ctx->msm, *ctx->poly));
     } catch (const ZkError &err) {
         g_init_error = err.what();
         int code = err.code;
@@ -94,6 +101,8 @@ void zkgpu_destroy(zkgpu_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->prover.reset();
+    ctx->poly.reset();
     ctx->ntt.reset();
     ctx->msm.reset();
     ctx->stage_a.release();
@@ -112,7 +121,8 @@ int zkgpu_sync(zkgpu_ctx *ctx) {
 
 size_t zkgpu_device_bytes(const zkgpu_ctx *ctx) {
     if (!ctx) return 0;
-    return ctx->ntt->device_bytes() + ctx->msm->device_bytes() + ctx->stage_a.cap + ctx->stage_b.cap;
+    return ctx->ntt->device_bytes() + ctx->msm->device_bytes() + ctx->poly->device_bytes() + ctx->prover->device_bytes() +
+           ctx->stage_a.cap + ctx->stage_b.cap;
 }
 
 int zkgpu_timer_start(zkgpu_ctx *ctx) {
@@ -286,6 +296,170 @@ int zkgpu_g1_compress(const uint64_t xy[12], uint8_t infinity, uint8_t out[48]) 
         }
         if (!borrow) out[0] |= 0x20;
     }
+    return ZKGPU_OK;
+}
+
+}  // extern "C"
+
+// ---- ProverKey / Prover -----------------------------------------------------------------------------------------
+static void affine_words(const AffineOut &a, uint64_t *xy, uint8_t *inf) {
+    memcpy(xy, a.x.v, 48);
+    memcpy(xy + 6, a.y.v, 48);
+    *inf = a.infinity ? 1 : 0;
+}
+
+extern "C" {
+
+int zkgpu_prover_key_load(zkgpu_ctx *ctx, uint32_t n, uint64_t constraints, const uint64_t *selector_evals,
+                          const char *label, size_t label_len, const uint64_t *pi_indexes, size_t n_pi) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(label != nullptr || label_len == 0, ZKGPU_ERR_INVALID_ARG, "prover_key_load: null label");
+        ZK_REQUIRE(pi_indexes != nullptr || n_pi == 0, ZKGPU_ERR_INVALID_ARG, "prover_key_load: null public input indexes");
+        ctx->prover->load_key(n, constraints, selector_evals, std::string(label ? label : "", label_len), pi_indexes, n_pi);
+    });
+}
+
+int zkgpu_prover_key_commitments(zkgpu_ctx *ctx, uint64_t *out_xy, uint8_t *out_infinity) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(ctx->prover->loaded(), ZKGPU_ERR_NOT_LOADED, "no prover key loaded");
+        ZK_REQUIRE(out_xy && out_infinity, ZKGPU_ERR_INVALID_ARG, "null output");
+        for (int k = 0; k < N_SEL; k++) affine_words(ctx->prover->selector_comms()[k], out_xy + 12 * k, out_infinity + k);
+    });
+}
+
+int zkgpu_prover_key_poly(zkgpu_ctx *ctx, int which, uint64_t *out) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(ctx->prover->loaded(), ZKGPU_ERR_NOT_LOADED, "no prover key loaded");
+        ZK_REQUIRE(which >= 0 && which < N_SEL && out, ZKGPU_ERR_INVALID_ARG, "prover_key_poly: bad argument");
+        ZK_HIP(hipMemcpyAsync(out, ctx->prover->key_poly(which), (size_t)ctx->prover->n() * sizeof(Fr), hipMemcpyDeviceToHost,
+                              ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int zkgpu_prover_key_eval8n(zkgpu_ctx *ctx, int which, uint64_t *out) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(ctx->prover->loaded(), ZKGPU_ERR_NOT_LOADED, "no prover key loaded");
+        ZK_REQUIRE(which >= 0 && which < N_SEL + 2 && out, ZKGPU_ERR_INVALID_ARG, "prover_key_eval8n: bad argument");
+        ZK_HIP(hipMemcpyAsync(out, ctx->prover->key_eval8n(which), (size_t)8 * ctx->prover->n() * sizeof(Fr),
+                              hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int zkgpu_quotient(zkgpu_ctx *ctx, const uint64_t *polys, const size_t lens[6], const uint64_t *challenges7,
+                   uint64_t *t_out, size_t *t_len) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(ctx->prover->loaded(), ZKGPU_ERR_NOT_LOADED, "no prover key loaded");
+        ZK_REQUIRE(polys && lens && challenges7 && t_out && t_len, ZKGPU_ERR_INVALID_ARG, "quotient: null argument");
+        const size_t n = ctx->prover->n(), N8 = 8 * n;
+        size_t total = 0;
+        for (int i = 0; i < 6; i++) total += lens[i];
+        ctx->stage_a.reserve((total + 1) * sizeof(Fr));
+        ctx->stage_b.reserve(N8 * sizeof(Fr));
+        if (total) ZK_HIP(hipMemcpyAsync(ctx->stage_a.p, polys, total * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        const Fr *base = ctx->stage_a.as<Fr>();
+        const Fr *ptr[6];
+        size_t off = 0;
+        for (int i = 0; i < 6; i++) {
+            ptr[i] = base + off;
+            off += lens[i];
+        }
+        const Fr *wires[4] = {ptr[1], ptr[2], ptr[3], ptr[4]};
+        const uint64_t wl[4] = {lens[1], lens[2], lens[3], lens[4]};
+        Fr ch[7];
+        memcpy(ch, challenges7, sizeof ch);
+        uint64_t len = ctx->prover->quotient(ptr[0], lens[0], wires, wl, ptr[5], lens[5], ch, ctx->stage_b.as<Fr>());
+        ZK_HIP(hipMemcpyAsync(t_out, ctx->stage_b.p, N8 * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        *t_len = (size_t)len;
+    });
+}
+
+int zkgpu_perm_z(zkgpu_ctx *ctx, uint32_t n, const uint64_t *wires, const uint64_t *sigma_evals, const uint64_t beta[4],
+                 const uint64_t gamma[4], uint64_t *z_out) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(wires && sigma_evals && beta && gamma && z_out, ZKGPU_ERR_INVALID_ARG, "perm_z: null argument");
+        ZK_REQUIRE(n >= 1 && (n & (n - 1)) == 0, ZKGPU_ERR_INVALID_ARG, "perm_z: n must be a power of two");
+        uint32_t log_n = 0;
+        while ((1u << log_n) < n) log_n++;
+        ctx->stage_a.reserve((size_t)9 * n * sizeof(Fr));
+        Fr *d = ctx->stage_a.as<Fr>();
+        ZK_HIP(hipMemcpyAsync(d, wires, (size_t)4 * n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(d + (size_t)4 * n, sigma_evals, (size_t)4 * n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        const Fr *w[4] = {d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n};
+        const Fr *sg[4] = {d + 4 * (size_t)n, d + 5 * (size_t)n, d + 6 * (size_t)n, d + 7 * (size_t)n};
+        Fr b, g;
+        memcpy(b.v, beta, 32);
+        memcpy(g.v, gamma, 32);
+        ctx->poly->permutation_z(w, sg, b, g, ctx->ntt->roots_half(log_n), n, d + 8 * (size_t)n);
+        ZK_HIP(hipMemcpyAsync(z_out, d + 8 * (size_t)n, (size_t)n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int zkgpu_poly_eval(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, const uint64_t x[4], uint64_t out[4]) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE((coeffs || len == 0) && x && out, ZKGPU_ERR_INVALID_ARG, "poly_eval: null argument");
+        ctx->stage_a.reserve((len + 2) * sizeof(Fr));
+        Fr *d = ctx->stage_a.as<Fr>();
+        if (len) ZK_HIP(hipMemcpyAsync(d + 1, coeffs, len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        EvalJob job;
+        job.coeffs = d + 1;
+        job.len = len;
+        memcpy(job.x.v, x, 32);
+        ctx->poly->evaluate(&job, 1, d);
+        ZK_HIP(hipMemcpyAsync(out, d, sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int zkgpu_poly_ruffini(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, const uint64_t root[4], uint64_t *out) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE((coeffs || len == 0) && root && (out || len <= 1), ZKGPU_ERR_INVALID_ARG, "poly_ruffini: null argument");
+        if (len <= 1) return;
+        ctx->stage_a.reserve(2 * len * sizeof(Fr));
+        Fr *d = ctx->stage_a.as<Fr>();
+        ZK_HIP(hipMemcpyAsync(d, coeffs, len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        Fr r;
+        memcpy(r.v, root, 32);
+        ctx->poly->ruffini(d, len, r, d + len);
+        ZK_HIP(hipMemcpyAsync(out, d + len, (len - 1) * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int zkgpu_prove(zkgpu_ctx *ctx, const uint64_t *wires, const uint64_t *public_inputs, size_t n_pi,
+                const uint64_t *blinders14, uint64_t *out_comms_xy, uint8_t *out_comms_infinity, uint64_t *out_evals15,
+                uint64_t *out_challenges10, float *timings8) {
+    int proof_rc = 0;
+    int rc = guarded(ctx, [&] {
+        ZK_REQUIRE(out_comms_xy && out_comms_infinity && out_evals15, ZKGPU_ERR_INVALID_ARG, "prove: null output");
+        ZK_REQUIRE(public_inputs != nullptr || n_pi == 0, ZKGPU_ERR_INVALID_ARG, "prove: null public inputs");
+        ProofOut proof;
+        ProveTimings tm;
+        memset(&tm, 0, sizeof tm);
+        proof_rc = ctx->prover->prove(wires, public_inputs, n_pi, blinders14, proof, timings8 ? &tm : nullptr);
+        if (proof_rc != 0) {
+            ctx->last_error = proof_rc == ZKGPU_ERR_DEGREE_ZERO    ? "PolynomialDegreeIsZero"
+                              : proof_rc == ZKGPU_ERR_DEGREE_LARGE ? "PolynomialDegreeTooLarge"
+                                                                   : "quotient polynomial shorter than 3n + 1";
+            return;
+        }
+        for (int i = 0; i < 11; i++) affine_words(proof.comms[i], out_comms_xy + 12 * i, out_comms_infinity + i);
+        memcpy(out_evals15, proof.evals, sizeof proof.evals);
+        if (out_challenges10) memcpy(out_challenges10, proof.challenges, sizeof proof.challenges);
+        if (timings8) memcpy(timings8, tm.ms, sizeof tm.ms);
+    });
+    return rc != 0 ? rc : proof_rc;
+}
+
+int zkgpu_transcript_challenge(const char *label, const char *msg_label, const uint8_t *msg, size_t msg_len,
+                               const char *ch_label, uint8_t *out, size_t out_len) {
+    if (!label || !msg_label || !ch_label || (!msg && msg_len) || !out) return ZKGPU_ERR_INVALID_ARG;
+    MerlinTranscript t(label);
+    t.append_message(msg_label, msg, msg_len);
+    t.challenge_bytes(ch_label, out, out_len);
     return ZKGPU_OK;
 }
 

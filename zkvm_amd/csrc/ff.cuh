@@ -188,6 +188,12 @@ struct Fp_ {
         return mul(a, o);
     }
     FF_HD static Fp_ to_mont(const Fp_ &a) { return mul(a, r2()); }
+    // small integer -> field element
+    FF_HD static Fp_ from_u32(uint32_t x) {
+        Fp_ o = zero();
+        o.v[0] = x;
+        return to_mont(o);
+    }
 
     FF_HD Fp_ operator+(const Fp_ &b) const { return add(*this, b); }
     FF_HD Fp_ operator-(const Fp_ &b) const { return sub(*this, b); }

@@ -280,6 +280,12 @@ void NttEngine::ensure_tables(uint32_t log_n) {
     table_log_ = log_n;
 }
 
+const Fr *NttEngine::roots_half(uint32_t log_n) {
+    ensure_tables(log_n ? log_n : 1);
+    // the stage with half-size h = n/2 holds w_n^i at entries h-1 .. 2h-2
+    return tw_fwd_.as<Fr>() + (log_n ? ((size_t)1 << (log_n - 1)) - 1 : 0);
+}
+
 const Fr *NttEngine::coset_inv_table(uint32_t log_n) {
     auto it = tw_cinv_.find(log_n);
     if (it != tw_cinv_.end()) return it->second.as<Fr>();

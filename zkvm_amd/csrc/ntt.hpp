@@ -26,6 +26,8 @@ class NttEngine {
     // Transforms `len_in` elements at `in` (zero-padded or truncated to 2^log_n, domain.rs:146) into the
     // 2^log_n elements at `out`; both are device pointers and may alias.  Asynchronous on the engine's stream.
     void transform(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n);
+    // w^i for i < n/2 of the 2^log_n domain (device pointer into the forward stage tables); log_n >= 1
+    const Fr *roots_half(uint32_t log_n);
     // Largest transform the twiddle tables currently cover (grown on demand).
     uint32_t table_log() const { return table_log_; }
     size_t device_bytes() const;

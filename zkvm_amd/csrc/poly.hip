@@ -1,0 +1,464 @@
+// Prover-side polynomial kernels for gfx950 (see poly.hpp).  All field results are canonical, so any order of
+// exact field operations gives the reference's limbs; the kernels are free to replace the reference's serial
+// recurrences (per-gate inversion + running product, Horner sums, synthetic division) by scans and reductions.
+#include "poly.hpp"
+#include "widgets.cuh"
+#include <vector>
+
+namespace zk {
+
+__device__ __forceinline__ Fr ld(const Fr *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void st(Fr *p, const Fr &r) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+// ---- inclusive scans over Fr --------------------------------------------------------------------------------
+struct OpMul {
+    __device__ static Fr id() { return Fr::one(); }
+    __device__ static Fr op(const Fr &a, const Fr &b) { return Fr::mul(a, b); }
+};
+struct OpAdd {
+    __device__ static Fr id() { return Fr::zero(); }
+    __device__ static Fr op(const Fr &a, const Fr &b) { return Fr::add(a, b); }
+};
+
+static const uint32_t SCAN_T = 256, SCAN_E = 4, SCAN_B = SCAN_T * SCAN_E;
+
+__device__ __forceinline__ void lds_st(uint32_t *sh, uint32_t slot, const Fr &r) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) sh[slot * 8 + i] = r.v[i];
+}
+__device__ __forceinline__ Fr lds_ld(const uint32_t *sh, uint32_t slot) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = sh[slot * 8 + i];
+    return r;
+}
+
+// Hillis-Steele inclusive scan of one value per thread across a 256-thread block; returns the exclusive prefix of
+// the calling thread and leaves the block total in *total (valid in every thread).
+template <class Op>
+__device__ __forceinline__ Fr block_exclusive(uint32_t *sh /* 2 * 256 * 8 words */, const Fr &mine, Fr *total) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t *cur = sh, *nxt = sh + SCAN_T * 8;
+    lds_st(cur, tid, mine);
+    __syncthreads();
+    for (uint32_t d = 1; d < SCAN_T; d <<= 1) {
+        Fr v = lds_ld(cur, tid);
+        if (tid >= d) v = Op::op(lds_ld(cur, tid - d), v);
+        lds_st(nxt, tid, v);
+        __syncthreads();
+        uint32_t *t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    *total = lds_ld(cur, SCAN_T - 1);
+    Fr ex = tid ? lds_ld(cur, tid - 1) : Op::id();
+    __syncthreads();
+    return ex;
+}
+
+// Logical element j lives at physical index j (forward) or n-1-j (reverse).
+template <class Op, bool REV>
+__global__ void __launch_bounds__(256) scan_local_kernel(const Fr *in, Fr *out, Fr *totals, uint64_t n) {
+    __shared__ uint32_t sh[2 * SCAN_T * 8];
+    const uint64_t j0 = (uint64_t)blockIdx.x * SCAN_B + (uint64_t)threadIdx.x * SCAN_E;
+    Fr v[SCAN_E];
+    Fr run = Op::id();
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_E; k++) {
+        uint64_t j = j0 + k;
+        Fr x = Op::id();
+        if (j < n) x = ld(in + (REV ? n - 1 - j : j));
+        run = Op::op(run, x);
+        v[k] = run;
+    }
+    Fr total;
+    Fr ex = block_exclusive<Op>(sh, run, &total);
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_E; k++) {
+        uint64_t j = j0 + k;
+        if (j < n) st(out + (REV ? n - 1 - j : j), Op::op(ex, v[k]));
+    }
+    if (threadIdx.x == 0) st(totals + blockIdx.x, total);
+}
+
+// exclusive scan of the block totals, in place (single workgroup, chunks of 256 with a running carry)
+template <class Op>
+__global__ void __launch_bounds__(256) scan_totals_kernel(Fr *totals, uint32_t n_blocks) {
+    __shared__ uint32_t sh[2 * SCAN_T * 8];
+    Fr carry = Op::id();
+    for (uint32_t start = 0; start < n_blocks; start += SCAN_T) {
+        uint32_t i = start + threadIdx.x;
+        Fr v = i < n_blocks ? ld(totals + i) : Op::id();
+        Fr total;
+        Fr ex = block_exclusive<Op>(sh, v, &total);
+        if (i < n_blocks) st(totals + i, Op::op(carry, ex));
+        carry = Op::op(carry, total);
+    }
+}
+
+template <class Op, bool REV>
+__global__ void __launch_bounds__(256) scan_apply_kernel(Fr *out, const Fr *totals, uint64_t n) {
+    if (blockIdx.x == 0) return;  // prefix of block 0 is the identity
+    const Fr pre = ld(totals + blockIdx.x);
+    const uint64_t j0 = (uint64_t)blockIdx.x * SCAN_B + (uint64_t)threadIdx.x * SCAN_E;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_E; k++) {
+        uint64_t j = j0 + k;
+        if (j < n) {
+            Fr *p = out + (REV ? n - 1 - j : j);
+            st(p, Op::op(pre, ld(p)));
+        }
+    }
+}
+
+template <class Op, bool REV>
+static void inclusive_scan(hipStream_t stream, const Fr *in, Fr *out, uint64_t n, DevBuf &totals) {
+    if (n == 0) return;
+    const uint32_t n_blocks = (uint32_t)((n + SCAN_B - 1) / SCAN_B);
+    totals.reserve((size_t)n_blocks * sizeof(Fr));
+    hipLaunchKernelGGL((scan_local_kernel<Op, REV>), dim3(n_blocks), dim3(SCAN_T), 0, stream, in, out, totals.as<Fr>(), n);
+    if (n_blocks > 1) {
+        hipLaunchKernelGGL((scan_totals_kernel<Op>), dim3(1), dim3(SCAN_T), 0, stream, totals.as<Fr>(), n_blocks);
+        hipLaunchKernelGGL((scan_apply_kernel<Op, REV>), dim3(n_blocks), dim3(SCAN_T), 0, stream, out, totals.as<Fr>(), n);
+    }
+    ZK_HIP(hipGetLastError());
+}
+
+// ---- permutation accumulator --------------------------------------------------------------------------------
+struct PermArgs {
+    const Fr *w[4];
+    const Fr *s[4];
+    const Fr *roots_half;
+    Fr beta, gamma;
+    uint32_t n;
+};
+
+__global__ void __launch_bounds__(256) perm_numden_kernel(PermArgs a, Fr *num, Fr *den) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t half = a.n >> 1;
+    Fr root;
+    if (a.n == 1) {
+        root = Fr::one();
+    } else {
+        root = ld(a.roots_half + (i & (half - 1)));
+        if (i >= half) root = Fr::neg(root);  // w^(i) = -w^(i - n/2)
+    }
+    const Fr br = Fr::mul(a.beta, root);
+    Fr w0 = ld(a.w[0] + i), w1 = ld(a.w[1] + i), w2 = ld(a.w[2] + i), w3 = ld(a.w[3] + i);
+    // K1, K2, K3 = 7, 13, 17 (plonk/src/composer/permutation/constants.rs:7-9)
+    Fr n0 = Fr::add(Fr::add(w0, br), a.gamma);
+    Fr n1 = Fr::add(Fr::add(w1, mul_small<7>(br)), a.gamma);
+    Fr n2 = Fr::add(Fr::add(w2, mul_small<13>(br)), a.gamma);
+    Fr n3 = Fr::add(Fr::add(w3, mul_small<17>(br)), a.gamma);
+    st(num + i, Fr::mul(Fr::mul(n0, n1), Fr::mul(n2, n3)));
+    Fr d0 = Fr::add(Fr::add(w0, Fr::mul(a.beta, ld(a.s[0] + i))), a.gamma);
+    Fr d1 = Fr::add(Fr::add(w1, Fr::mul(a.beta, ld(a.s[1] + i))), a.gamma);
+    Fr d2 = Fr::add(Fr::add(w2, Fr::mul(a.beta, ld(a.s[2] + i))), a.gamma);
+    Fr d3 = Fr::add(Fr::add(w3, Fr::mul(a.beta, ld(a.s[3] + i))), a.gamma);
+    st(den + i, Fr::mul(Fr::mul(d0, d1), Fr::mul(d2, d3)));
+}
+
+// z[i] = (prod_{j<i} num_j) * (prod_{j>=i} den_j) / (prod_j den_j)
+__global__ void __launch_bounds__(256) perm_finish_kernel(const Fr *pnum_incl, const Fr *sden_incl, uint32_t n, Fr *z) {
+    __shared__ uint32_t inv_sh[8];
+    if (threadIdx.x == 0) lds_st(inv_sh, 0, Fr::inv(ld(sden_incl)));
+    __syncthreads();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr inv_total = lds_ld(inv_sh, 0);
+    Fr v = Fr::mul(ld(sden_incl + i), inv_total);
+    if (i) v = Fr::mul(v, ld(pnum_incl + i - 1));
+    st(z + i, v);
+}
+
+void PolyEngine::permutation_z(const Fr *const wires[4], const Fr *const sigma_evals[4], const Fr &beta, const Fr &gamma,
+                               const Fr *roots_half, uint32_t n, Fr *z_out) {
+    ZK_REQUIRE(n >= 1, ZKGPU_ERR_INVALID_ARG, "permutation_z: empty domain");
+    s0_.reserve((size_t)n * sizeof(Fr));
+    s1_.reserve((size_t)n * sizeof(Fr));
+    PermArgs a;
+    for (int k = 0; k < 4; k++) {
+        a.w[k] = wires[k];
+        a.s[k] = sigma_evals[k];
+    }
+    a.roots_half = roots_half;
+    a.beta = beta;
+    a.gamma = gamma;
+    a.n = n;
+    Fr *num = s0_.as<Fr>(), *den = s1_.as<Fr>();
+    hipLaunchKernelGGL(perm_numden_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, a, num, den);
+    inclusive_scan<OpMul, false>(stream_, num, num, n, s2_);
+    inclusive_scan<OpMul, true>(stream_, den, den, n, s2_);
+    hipLaunchKernelGGL(perm_finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, num, den, n, z_out);
+    ZK_HIP(hipGetLastError());
+}
+
+// ---- quotient -----------------------------------------------------------------------------------------------
+// The quotient kernel evaluates ~30 (arithmetic-only circuits) to ~150 field products per point; one out-of-line
+// product keeps the kernel inside the instruction cache.
+static __device__ __noinline__ Fr fr_mul_outlined(Fr a, Fr b) { return Fr::mul(a, b); }
+struct OutlinedMul {
+    __device__ __forceinline__ static Fr mul(const Fr &a, const Fr &b) { return fr_mul_outlined(a, b); }
+};
+#define FM(a, b) fr_mul_outlined((a), (b))
+
+__global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs q) {
+    typedef OutlinedMul M;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.n8) return;
+    const uint32_t iw = (i + 8) & (q.n8 - 1);  // "next row" on the 8n coset (quotient_poly.rs:53-59,134-136)
+    const Fr a = ld(q.a + i), b = ld(q.b + i), c = ld(q.c + i), d = ld(q.d + i);
+
+    // arithmetic/proverkey.rs:43-73
+    Fr t = FM(FM(a, b), ld(q.sel[Q_M] + i));
+    t = Fr::add(t, FM(a, ld(q.sel[Q_L] + i)));
+    t = Fr::add(t, FM(b, ld(q.sel[Q_R] + i)));
+    t = Fr::add(t, FM(c, ld(q.sel[Q_O] + i)));
+    t = Fr::add(t, FM(d, ld(q.sel[Q_F] + i)));
+    t = Fr::add(t, ld(q.sel[Q_C] + i));
+    t = FM(t, ld(q.sel[Q_ARITH] + i));
+
+    if (q.widgets) {  // every other widget is multiplied by its selector: zero selectors contribute exactly 0
+        const Fr a_w = ld(q.a + iw), b_w = ld(q.b + iw), d_w = ld(q.d + iw);
+        if (q.widgets & 1u) {  // range/proverkey.rs:31-59
+            Fr s = w_range_identity<M>(q.range_ch, a, b, c, d, d_w);
+            t = Fr::add(t, FM(FM(s, ld(q.sel[Q_RANGE] + i)), q.range_ch));
+        }
+        if (q.widgets & 2u) {  // logic/proverkey.rs:34-78
+            Fr s = w_logic_identity<M>(q.logic_ch, a, a_w, b, b_w, c, d, d_w, ld(q.sel[Q_C] + i));
+            t = Fr::add(t, FM(FM(ld(q.sel[Q_LOGIC] + i), s), q.logic_ch));
+        }
+        if (q.widgets & 4u) {  // ecc/scalar_mul/fixed_base/proverkey.rs:38-101
+            Fr s = w_fixed_base_identity<M>(q.fixed_ch, a, a_w, b, b_w, c, d, d_w, ld(q.sel[Q_L] + i), ld(q.sel[Q_R] + i),
+                                            ld(q.sel[Q_C] + i));
+            t = Fr::add(t, FM(FM(s, ld(q.sel[Q_FIXED] + i)), q.fixed_ch));
+        }
+        if (q.widgets & 8u) {  // ecc/curve_addition/proverkey.rs:32-83
+            Fr s = w_curve_add_identity<M>(q.var_ch, a, a_w, b, b_w, c, d, d_w);
+            t = Fr::add(t, FM(FM(s, ld(q.sel[Q_VAR] + i)), q.var_ch));
+        }
+    }
+    t = Fr::add(t, ld(q.pi + i));
+
+    // permutation/proverkey.rs:39-119
+    const Fr z = ld(q.z + i), z_w = ld(q.z + iw);
+    const Fr bx = FM(q.beta, ld(q.linear + i));
+    Fr id = Fr::add(Fr::add(a, bx), q.gamma);
+    id = FM(id, Fr::add(Fr::add(b, mul_small<7>(bx)), q.gamma));
+    id = FM(id, Fr::add(Fr::add(c, mul_small<13>(bx)), q.gamma));
+    id = FM(id, Fr::add(Fr::add(d, mul_small<17>(bx)), q.gamma));
+    id = FM(id, z);
+    Fr cp = Fr::add(Fr::add(a, FM(q.beta, ld(q.sel[S1] + i))), q.gamma);
+    cp = FM(cp, Fr::add(Fr::add(b, FM(q.beta, ld(q.sel[S2] + i))), q.gamma));
+    cp = FM(cp, Fr::add(Fr::add(c, FM(q.beta, ld(q.sel[S3] + i))), q.gamma));
+    cp = FM(cp, Fr::add(Fr::add(d, FM(q.beta, ld(q.sel[S4] + i))), q.gamma));
+    cp = FM(cp, z_w);
+    Fr p = FM(Fr::sub(id, cp), q.alpha);  // id * alpha - cp * alpha
+    // (z - 1) * L1 * alpha^2 ; q.l1 holds L1 on the coset, q.alpha_sq = alpha^2
+    p = Fr::add(p, FM(FM(Fr::sub(z, Fr::one()), ld(q.l1 + i)), q.alpha_sq));
+
+    // quotient_poly.rs:88-95: numerator / Z_H ; Z_H takes 8 values on the 8n coset
+    st(q.out + i, FM(Fr::add(t, p), q.vh_inv[i & 7]));
+}
+
+void PolyEngine::quotient(const QuotientArgs &args) {
+    ZK_REQUIRE(args.n8 >= 8 && (args.n8 & (args.n8 - 1)) == 0, ZKGPU_ERR_INVALID_ARG, "quotient: 8n must be a power of two");
+    hipLaunchKernelGGL(quotient_kernel, dim3(ceil_div(args.n8, 256)), dim3(256), 0, stream_, args);
+    ZK_HIP(hipGetLastError());
+}
+
+// ---- evaluation at a point ----------------------------------------------------------------------------------
+static const uint32_t EVAL_BLOCKS = 64, EVAL_T = 256, EVAL_STRIDE = EVAL_BLOCKS * EVAL_T;
+struct EvalJobDev {
+    const Fr *coeffs;
+    uint64_t len;
+    Fr x, x_stride;  // x^EVAL_STRIDE
+};
+
+// Thread t of the job sums c[t + m*STRIDE] * (x^STRIDE)^m by Horner (coalesced loads), scales by x^t, and the
+// block adds its 256 values.
+__global__ void __launch_bounds__(256) eval_partial_kernel(const EvalJobDev *jobs, Fr *partials) {
+    __shared__ uint32_t sh[2 * SCAN_T * 8];
+    const EvalJobDev *job = jobs + blockIdx.y;
+    const uint64_t len = job->len;
+    const uint32_t t = blockIdx.x * EVAL_T + threadIdx.x;
+    Fr acc = Fr::zero();
+    if (t < len) {
+        const Fr xs = ld(&job->x_stride);
+        uint64_t m = (len - 1 - t) / EVAL_STRIDE;  // highest multiple with t + m*STRIDE < len
+        const Fr *p = job->coeffs + t;
+        acc = ld(p + m * EVAL_STRIDE);
+        while (m > 0) {
+            m--;
+            acc = Fr::add(Fr::mul(acc, xs), ld(p + m * EVAL_STRIDE));
+        }
+        if (t) acc = Fr::mul(acc, Fr::pow_u64(ld(&job->x), t));
+    }
+    Fr total;
+    (void)block_exclusive<OpAdd>(sh, acc, &total);
+    if (threadIdx.x == 0) st(partials + blockIdx.y * EVAL_BLOCKS + blockIdx.x, total);
+}
+__global__ void __launch_bounds__(64) eval_final_kernel(const Fr *partials, Fr *out) {
+    // one wave per job: lane l holds partial l, tree-add through LDS
+    __shared__ uint32_t sh[64 * 8];
+    lds_st(sh, threadIdx.x, ld(partials + blockIdx.x * EVAL_BLOCKS + threadIdx.x));
+    __syncthreads();
+    for (uint32_t s = 32; s >= 1; s >>= 1) {
+        if (threadIdx.x < s) lds_st(sh, threadIdx.x, Fr::add(lds_ld(sh, threadIdx.x), lds_ld(sh, threadIdx.x + s)));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st(out + blockIdx.x, lds_ld(sh, 0));
+}
+
+void PolyEngine::evaluate(const EvalJob *jobs, int n_jobs, Fr *out_dev) {
+    if (n_jobs <= 0) return;
+    std::vector<EvalJobDev> h(n_jobs);
+    for (int j = 0; j < n_jobs; j++) {
+        h[j].coeffs = jobs[j].coeffs;
+        h[j].len = jobs[j].len;
+        h[j].x = jobs[j].x;
+        h[j].x_stride = Fr::pow_u64(jobs[j].x, EVAL_STRIDE);
+    }
+    const size_t job_bytes = (size_t)n_jobs * sizeof(EvalJobDev);
+    jobs_.reserve(job_bytes + (size_t)n_jobs * EVAL_BLOCKS * sizeof(Fr));
+    Fr *partials = reinterpret_cast<Fr *>(jobs_.as<char>() + job_bytes);
+    // the staging vector is a host temporary: finish the copy before it goes out of scope
+    ZK_HIP(hipMemcpyAsync(jobs_.p, h.data(), job_bytes, hipMemcpyHostToDevice, stream_));
+    ZK_HIP(hipStreamSynchronize(stream_));
+    hipLaunchKernelGGL(eval_partial_kernel, dim3(EVAL_BLOCKS, n_jobs), dim3(EVAL_T), 0, stream_, jobs_.as<EvalJobDev>(), partials);
+    hipLaunchKernelGGL(eval_final_kernel, dim3(n_jobs), dim3(64), 0, stream_, partials, out_dev);
+    ZK_HIP(hipGetLastError());
+}
+
+// ---- linear combination -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lincomb_kernel(LinArgs a) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.out_len) return;
+    Fr acc = i == 0 ? a.constant : Fr::zero();
+    for (int k = 0; k < a.n_terms; k++)
+        if (i < a.t[k].len) acc = Fr::add(acc, Fr::mul(a.t[k].scalar, ld(a.t[k].coeffs + i)));
+    st(a.out + i, acc);
+}
+void PolyEngine::linear_combination(const LinArgs &args) {
+    ZK_REQUIRE(args.n_terms >= 0 && args.n_terms <= MAX_LIN_TERMS, ZKGPU_ERR_INVALID_ARG, "linear_combination: too many terms");
+    if (args.out_len == 0) return;
+    hipLaunchKernelGGL(lincomb_kernel, dim3(ceil_div(args.out_len, 256)), dim3(256), 0, stream_, args);
+    ZK_HIP(hipGetLastError());
+}
+
+// ---- synthetic division -------------------------------------------------------------------------------------
+// q_i = sum_{k>i} c_k z^(k-i-1).  With d_k = c_k z^k and T_i = sum_{k>=i} d_k (a reverse additive scan):
+// q_i = T_{i+1} * z^-(i+1).  Powers are produced per thread from one pow and a running product.
+static const uint32_t POW_E = 8;
+template <bool SHIFTED>
+__global__ void __launch_bounds__(256) scale_powers_kernel(const Fr *in, Fr *out, uint64_t n, Fr base) {
+    // SHIFTED = false: out[k] = in[k] * base^k ;  SHIFTED = true: out[k] = in[k+1] * base^(k+1)
+    uint64_t k0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * POW_E;
+    if (k0 >= n) return;
+    Fr p = Fr::pow_u64(base, k0 + (SHIFTED ? 1 : 0));
+#pragma unroll
+    for (uint32_t e = 0; e < POW_E; e++) {
+        uint64_t k = k0 + e;
+        if (k >= n) break;
+        st(out + k, Fr::mul(ld(in + k + (SHIFTED ? 1 : 0)), p));
+        p = Fr::mul(p, base);
+    }
+}
+__global__ void shift_copy_kernel(const Fr *in, Fr *out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st(out + i, ld(in + i + 1));
+}
+
+void PolyEngine::ruffini(const Fr *coeffs, uint64_t len, const Fr &root, Fr *out) {
+    if (len <= 1) return;  // the quotient is empty
+    const uint64_t m = len - 1;
+    if (root.is_zero()) {  // q_i = c_{i+1}
+        hipLaunchKernelGGL(shift_copy_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, stream_, coeffs, out, m);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
+    s3_.reserve((size_t)len * sizeof(Fr));
+    Fr *tmp = s3_.as<Fr>();
+    const Fr root_inv = Fr::inv(root);
+    hipLaunchKernelGGL((scale_powers_kernel<false>), dim3(ceil_div(ceil_div(len, POW_E), 256)), dim3(256), 0, stream_, coeffs, tmp, len, root);
+    inclusive_scan<OpAdd, true>(stream_, tmp, tmp, len, s2_);
+    hipLaunchKernelGGL((scale_powers_kernel<true>), dim3(ceil_div(ceil_div(m, POW_E), 256)), dim3(256), 0, stream_, tmp, out, m, root_inv);
+    ZK_HIP(hipGetLastError());
+}
+
+// ---- single-coefficient edits -------------------------------------------------------------------------------
+struct PatchArgs {
+    uint64_t idx[8];
+    Fr val[8];
+    uint32_t sub[8];
+    int count;
+};
+__global__ void patch_kernel(Fr *p, PatchArgs a) {
+    int k = threadIdx.x;
+    if (k >= a.count) return;
+    Fr v = a.val[k];
+    if (a.sub[k]) v = Fr::sub(ld(p + a.idx[k]), v);
+    st(p + a.idx[k], v);
+}
+void PolyEngine::patch(Fr *p, const uint64_t *idx, const Fr *vals, const bool *sub, int count) {
+    ZK_REQUIRE(count >= 0 && count <= 8, ZKGPU_ERR_INVALID_ARG, "patch: at most 8 edits");
+    if (!count) return;
+    PatchArgs a;
+    a.count = count;
+    for (int k = 0; k < count; k++) {
+        a.idx[k] = idx[k];
+        a.val[k] = vals[k];
+        a.sub[k] = sub[k] ? 1 : 0;
+    }
+    hipLaunchKernelGGL(patch_kernel, dim3(1), dim3(64), 0, stream_, p, a);
+    ZK_HIP(hipGetLastError());
+}
+
+// ---- degree -------------------------------------------------------------------------------------------------
+// *out = 1 + index of the highest non-zero coefficient (0 for the zero polynomial)
+__global__ void __launch_bounds__(256) degree_kernel(const Fr *coeffs, uint64_t len, unsigned long long *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long mine = 0;
+    if (i < len && !ld(coeffs + i).is_zero()) mine = i + 1;
+    // wave-level maximum first, then one atomic per wave
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned long long o = __shfl_xor(mine, d);
+        mine = o > mine ? o : mine;
+    }
+    if ((threadIdx.x & 63) == 0 && mine) atomicMax(out, mine);
+}
+uint64_t PolyEngine::length_without_leading_zeros(const Fr *coeffs, uint64_t len) {
+    if (len == 0) return 0;
+    jobs_.reserve(64);
+    unsigned long long *d = jobs_.as<unsigned long long>();
+    ZK_HIP(hipMemsetAsync(d, 0, 8, stream_));
+    hipLaunchKernelGGL(degree_kernel, dim3(ceil_div(len, 256)), dim3(256), 0, stream_, coeffs, len, d);
+    ZK_HIP(hipGetLastError());
+    unsigned long long h = 0;
+    ZK_HIP(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream_));
+    ZK_HIP(hipStreamSynchronize(stream_));
+    return (uint64_t)h;
+}
+
+PolyEngine::~PolyEngine() {
+    s0_.release();
+    s1_.release();
+    s2_.release();
+    s3_.release();
+    jobs_.release();
+}
+
+}  // namespace zk

@@ -1,0 +1,76 @@
+// Device kernels for the prover's polynomial work around the NTT and the MSM: the permutation accumulator,
+// the fused quotient evaluation over the 8n coset, evaluation at a point, linear combinations and synthetic
+// division.  All pointers are device pointers; everything is asynchronous on the engine's stream.
+#pragma once
+#include "common.hpp"
+#include "ff.cuh"
+
+namespace zk {
+
+// Selector / sigma order shared with the oracle and the C boundary.
+enum Sel { Q_M, Q_L, Q_R, Q_O, Q_F, Q_C, Q_ARITH, Q_RANGE, Q_LOGIC, Q_FIXED, Q_VAR, S1, S2, S3, S4, N_SEL };
+
+struct QuotientArgs {
+    const Fr *z, *a, *b, *c, *d, *pi;  // 8n coset evaluations of the round polynomials
+    const Fr *sel[N_SEL];              // 8n coset evaluations of the selector and sigma polynomials
+    const Fr *linear;                  // X on the coset (ProverKey.permutation.linear_evaluations)
+    const Fr *l1;                      // L_1 on the coset (unscaled)
+    Fr *out;                           // numerator / Z_H
+    Fr alpha, alpha_sq, beta, gamma, range_ch, logic_ch, fixed_ch, var_ch;
+    Fr vh_inv[8];                      // 1 / Z_H on the coset has period 8
+    uint32_t n8;                       // 8n
+    uint32_t widgets;                  // bit 0 range, 1 logic, 2 fixed-base, 3 curve-addition: selector is non-zero
+};
+
+struct EvalJob {
+    const Fr *coeffs;
+    uint64_t len;
+    Fr x;
+};
+
+struct LinTerm {
+    const Fr *coeffs;
+    uint64_t len;
+    Fr scalar;
+};
+static const int MAX_LIN_TERMS = 18;
+struct LinArgs {
+    LinTerm t[MAX_LIN_TERMS];
+    int n_terms;
+    Fr constant;  // added to coefficient 0
+    Fr *out;
+    uint64_t out_len;
+};
+
+class PolyEngine {
+   public:
+    explicit PolyEngine(hipStream_t s) : stream_(s) {}
+    ~PolyEngine();
+
+    // z[0] = 1, z[i+1] = z[i] * prod_w (wire_w[i] + beta k_w root^i + gamma) / prod_w (wire_w[i] + beta sigma_w[i] + gamma)
+    // (plonk/src/composer/permutation.rs:181-245).  `roots` = w^i for i < n/2 (the rest is -w^(i-n/2)).
+    void permutation_z(const Fr *const wires[4], const Fr *const sigma_evals[4], const Fr &beta, const Fr &gamma,
+                       const Fr *roots_half, uint32_t n, Fr *z_out);
+    // Pointwise quotient over the 8n coset (plonk/src/proof_system/quotient_poly.rs:88-95,128-190,218-234).
+    void quotient(const QuotientArgs &args);
+    // out[j] = sum_i coeffs_j[i] * x_j^i  (plonk/src/fft/polynomial.rs:105-119), results in device memory
+    void evaluate(const EvalJob *jobs, int n_jobs, Fr *out_dev);
+    // out[i] = sum_k scalar_k * P_k[i] (+ constant at i = 0)
+    void linear_combination(const LinArgs &args);
+    // quotient of division by (X - root), remainder dropped (plonk/src/fft/polynomial.rs:343-357); out has len-1 entries
+    void ruffini(const Fr *coeffs, uint64_t len, const Fr &root, Fr *out);
+    // small edits of single coefficients: p[idx] = p[idx] - v (sub = true) or p[idx] = v
+    void patch(Fr *p, const uint64_t *idx, const Fr *vals, const bool *sub, int count);
+
+    // number of coefficients once leading zeros are dropped (Polynomial::truncate_leading_zeros,
+    // plonk/src/fft/polynomial.rs:95-103); synchronises the stream
+    uint64_t length_without_leading_zeros(const Fr *coeffs, uint64_t len);
+
+    size_t device_bytes() const { return s0_.cap + s1_.cap + s2_.cap + s3_.cap + jobs_.cap; }
+
+   private:
+    hipStream_t stream_;
+    DevBuf s0_, s1_, s2_, s3_, jobs_;
+};
+
+}  // namespace zk

@@ -1,0 +1,548 @@
+// Host orchestration of preprocess and prove over the device engines (see prover.hpp).
+#include "prover.hpp"
+#include "widgets.cuh"
+#include <chrono>
+#include <cstring>
+
+namespace zk {
+
+// ---- host field helpers ---------------------------------------------------------------------------------------
+static Fr fr_from_words(const uint64_t w[4]) {
+    Fr r;
+    memcpy(r.v, w, 32);
+    return r;
+}
+// Scalar::from_bytes_wide (coset-bls12_381/src/scalar.rs:282-303): d0 * R^2 + d1 * R^3
+static Fr fr_from_bytes_wide(const uint8_t b[64]) {
+    Fr d0, d1, r3;
+    memcpy(d0.v, b, 32);
+    memcpy(d1.v, b + 32, 32);
+    const uint64_t R3[4] = {0xc62c1807439b73afULL, 0x1b3e0d188cf06990ULL, 0x73d13c71c7b5f418ULL, 0x6e2a5bb9c8db33e9ULL};
+    memcpy(r3.v, R3, 32);
+    return Fr::add(Fr::mul(d0, Fr::r2()), Fr::mul(d1, r3));
+}
+static Fr fr_u64(uint64_t x) {
+    Fr o = Fr::zero();
+    o.v[0] = (uint32_t)x;
+    o.v[1] = (uint32_t)(x >> 32);
+    return Fr::to_mont(o);
+}
+
+// plonk/src/transcript.rs:30-66
+struct PlonkTranscript {
+    MerlinTranscript t;
+    explicit PlonkTranscript(const std::string &label) : t(label) {}
+    void append_commitment(const char *label, const AffineOut &c) {
+        uint64_t xy[12];
+        uint8_t out[48];
+        memcpy(xy, c.x.v, 48);
+        memcpy(xy + 6, c.y.v, 48);
+        zkgpu_g1_compress(xy, c.infinity ? 1 : 0, out);
+        t.append_message(label, out, 48);
+    }
+    void append_scalar(const char *label, const Fr &s) {
+        Fr c = Fr::from_mont(s);  // Scalar::to_bytes: canonical little-endian
+        t.append_message(label, c.v, 32);
+    }
+    Fr challenge_scalar(const char *label) {
+        uint8_t buf[64];
+        t.challenge_bytes(label, buf, 64);
+        return fr_from_bytes_wide(buf);
+    }
+    void circuit_domain_sep(uint64_t n) {
+        t.append_message("dom-sep", "circuit_size", 12);
+        t.append_u64("n", n);
+    }
+};
+
+static AffineOut to_affine(const G1Proj &p) {
+    AffineOut o;
+    g1_to_affine(p, o.x, o.y, o.infinity);
+    return o;
+}
+static AffineOut affine_identity() {
+    AffineOut o;
+    o.x = Fq::zero();
+    o.y = Fq::one();
+    o.infinity = true;
+    return o;
+}
+
+// util::batch_inversion semantics on a handful of host scalars (zeros stay zero)
+static void host_batch_inverse(std::vector<Fr> &v) {
+    for (auto &x : v) x = Fr::inv(x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+Prover::~Prover() {
+    polys_.release();
+    evals_.release();
+    sigma_.release();
+    work_.release();
+    small_.release();
+}
+
+size_t Prover::device_bytes() const { return polys_.cap + evals_.cap + sigma_.cap + work_.cap + small_.cap; }
+
+const Fr *Prover::key_eval8n(int k) const { return reinterpret_cast<const Fr *>(evals_.p) + (size_t)k * 8 * n_; }
+
+int Prover::commit_dev(const Fr *coeffs, uint64_t len, AffineOut &out) {
+    const uint64_t eff = poly_.length_without_leading_zeros(coeffs, len);
+    const uint64_t degree = eff ? eff - 1 : 0;  // Polynomial::degree (polynomial.rs:79-93)
+    if (degree == 0) return ZKGPU_ERR_DEGREE_ZERO;
+    if (degree > msm_.n_points() - 1) return ZKGPU_ERR_DEGREE_LARGE;
+    out = to_affine(msm_.msm(coeffs, eff, 0));
+    return 0;
+}
+
+void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector_evals_host, const std::string &label,
+                      const uint64_t *pi_indexes, size_t n_pi) {
+    ZK_REQUIRE(n >= 1 && (n & (n - 1)) == 0, ZKGPU_ERR_INVALID_ARG, "prover_key_load: n must be a power of two");
+    ZK_REQUIRE(selector_evals_host != nullptr, ZKGPU_ERR_INVALID_ARG, "prover_key_load: null selectors");
+    ZK_REQUIRE(msm_.n_points() > 0, ZKGPU_ERR_NOT_LOADED, "prover_key_load: load the SRS first");
+    ZK_REQUIRE((uint64_t)n * 8 < (1ull << 32), ZKGPU_ERR_DOMAIN_SIZE, "InvalidEvalDomainSize: 8n must be below 2^32");
+    n_ = 0;
+    uint32_t log_n = 0;
+    while ((1u << log_n) < n) log_n++;
+    const size_t N8 = (size_t)8 * n;
+    polys_.reserve((size_t)N_SEL * n * sizeof(Fr));
+    evals_.reserve((size_t)(N_SEL + 2) * N8 * sizeof(Fr));
+    sigma_.reserve((size_t)4 * n * sizeof(Fr));
+    work_.reserve((size_t)N_SEL * n * sizeof(Fr));
+    Fr *stage = work_.as<Fr>();
+    Fr *polys = polys_.as<Fr>();
+    Fr *evals = evals_.as<Fr>();
+    ZK_HIP(hipMemcpyAsync(stage, selector_evals_host, (size_t)N_SEL * n * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+    ZK_HIP(hipMemcpyAsync(sigma_.p, stage + (size_t)S1 * n, (size_t)4 * n * sizeof(Fr), hipMemcpyDeviceToDevice, stream_));
+    n_ = n;
+    log_n_ = log_n;
+    constraints_ = constraints;
+    label_ = label;
+    pi_indexes_.assign(pi_indexes, pi_indexes + n_pi);
+    widgets_ = 0;
+    for (int k = 0; k < N_SEL; k++) {
+        // compiler.rs:123-147 (selectors) and permutation.rs:164-171 (sigmas): ifft, leading zeros dropped
+        ntt_.transform(NTT_IFFT, stage + (size_t)k * n, n, polys + (size_t)k * n, log_n);
+        poly_len_[k] = poly_.length_without_leading_zeros(polys + (size_t)k * n, n);
+        // compiler.rs:241-301: coset_fft over the 8n domain
+        ntt_.transform(NTT_COSET_FFT, polys + (size_t)k * n, poly_len_[k], evals + (size_t)k * N8, log_n + 3);
+    }
+    if (poly_len_[Q_RANGE]) widgets_ |= 1u;
+    if (poly_len_[Q_LOGIC]) widgets_ |= 2u;
+    if (poly_len_[Q_FIXED]) widgets_ |= 4u;
+    if (poly_len_[Q_VAR]) widgets_ |= 8u;
+    {
+        // compiler.rs:303-306: linear_evaluations = coset_fft([0, 1]) ; L1 = coset_fft(ifft([1, 0, 0, ...]))
+        // (quotient_poly.rs:237-245 builds alpha^2 * L1 per proof; alpha^2 is applied inside the quotient kernel)
+        std::vector<Fr> two(2);
+        two[0] = Fr::zero();
+        two[1] = Fr::one();
+        Fr *tmp = stage;  // selector staging is no longer needed
+        ZK_HIP(hipMemcpyAsync(tmp, two.data(), 2 * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+        ZK_HIP(hipStreamSynchronize(stream_));
+        ntt_.transform(NTT_COSET_FFT, tmp, 2, evals + (size_t)N_SEL * N8, log_n + 3);
+        Fr one = Fr::one();
+        ZK_HIP(hipMemcpyAsync(tmp, &one, sizeof(Fr), hipMemcpyHostToDevice, stream_));
+        ZK_HIP(hipStreamSynchronize(stream_));
+        ntt_.transform(NTT_IFFT, tmp, 1, tmp, log_n);
+        ntt_.transform(NTT_COSET_FFT, tmp, n, evals + (size_t)(N_SEL + 1) * N8, log_n + 3);
+    }
+    {
+        // compute_vanishing_poly_over_coset (domain.rs:256-275): v_h[i] = g^n * w_8n^(n i) - 1, period 8
+        Domain d8 = Domain::make(N8);
+        Fr g = Fr::inv(d8.generator_inv);
+        Fr gn = Fr::pow_u64(g, n);
+        Fr w8 = Fr::pow_u64(d8.group_gen, n);
+        Fr cur = Fr::one();
+        for (int i = 0; i < 8; i++) {
+            vh_inv_[i] = Fr::inv(Fr::sub(Fr::mul(gn, cur), Fr::one()));
+            cur = Fr::mul(cur, w8);
+        }
+    }
+    // compiler.rs:152-171: selector commitments default to the identity on error, sigma commitments must succeed
+    for (int k = 0; k < N_SEL; k++) {
+        int rc = commit_dev(polys + (size_t)k * n, poly_len_[k], sel_comms_[k]);
+        if (rc != 0) {
+            if (k >= S1) {
+                n_ = 0;
+                throw ZkError(rc, "prover_key_load: sigma polynomial cannot be committed");
+            }
+            sel_comms_[k] = affine_identity();
+        }
+    }
+}
+
+void Prover::blind_poly(const Fr *evals_dev, int hiding_degree, const Fr *blinders, Fr *out_dev) {
+    // prover.rs:64-83
+    ntt_.transform(NTT_IFFT, evals_dev, n_, out_dev, log_n_);
+    uint64_t idx[8];
+    Fr vals[8];
+    bool sub[8];
+    int k = 0;
+    for (int i = 0; i <= hiding_degree; i++) {
+        idx[k] = i;
+        vals[k] = blinders[i];
+        sub[k++] = true;
+        idx[k] = (uint64_t)n_ + i;
+        vals[k] = blinders[i];
+        sub[k++] = false;
+    }
+    poly_.patch(out_dev, idx, vals, sub, k);
+}
+
+uint64_t Prover::quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4], const uint64_t wire_len[4], const Fr *pi,
+                          uint64_t pi_len, const Fr ch[7], Fr *t_out) {
+    ZK_REQUIRE(loaded(), ZKGPU_ERR_NOT_LOADED, "quotient: no prover key loaded");
+    const size_t N8 = (size_t)8 * n_;
+    small_.reserve(6 * N8 * sizeof(Fr));
+    Fr *ev = small_.as<Fr>();
+    const uint32_t lg8 = log_n_ + 3;
+    // quotient_poly.rs:46-51,120
+    ntt_.transform(NTT_COSET_FFT, z, z_len, ev, lg8);
+    for (int k = 0; k < 4; k++) ntt_.transform(NTT_COSET_FFT, wires[k], wire_len[k], ev + (size_t)(k + 1) * N8, lg8);
+    ntt_.transform(NTT_COSET_FFT, pi, pi_len, ev + 5 * N8, lg8);
+    QuotientArgs q;
+    q.z = ev;
+    q.a = ev + N8;
+    q.b = ev + 2 * N8;
+    q.c = ev + 3 * N8;
+    q.d = ev + 4 * N8;
+    q.pi = ev + 5 * N8;
+    for (int k = 0; k < N_SEL; k++) q.sel[k] = key_eval8n(k);
+    q.linear = key_eval8n(N_SEL);
+    q.l1 = key_eval8n(N_SEL + 1);
+    q.out = t_out;
+    q.alpha = ch[0];
+    q.alpha_sq = Fr::sqr(ch[0]);
+    q.beta = ch[1];
+    q.gamma = ch[2];
+    q.range_ch = ch[3];
+    q.logic_ch = ch[4];
+    q.fixed_ch = ch[5];
+    q.var_ch = ch[6];
+    for (int i = 0; i < 8; i++) q.vh_inv[i] = vh_inv_[i];
+    q.n8 = (uint32_t)N8;
+    q.widgets = widgets_;
+    poly_.quotient(q);
+    ntt_.transform(NTT_COSET_IFFT, t_out, N8, t_out, lg8);  // quotient_poly.rs:97
+    return poly_.length_without_leading_zeros(t_out, N8);    // Polynomial::from_coefficients_vec
+}
+
+// proof_system/proof.rs:511-561
+static Fr barycentric_eval(const std::vector<Fr> &evaluations, const Fr &point, const Domain &domain) {
+    Fr numerator = Fr::mul(Fr::sub(Fr::pow_u64(point, domain.size), Fr::one()), domain.size_inv);
+    std::vector<size_t> nz;
+    for (size_t i = 0; i < evaluations.size(); i++)
+        if (!evaluations[i].is_zero()) nz.push_back(i);
+    std::vector<Fr> den(nz.size());
+    for (size_t k = 0; k < nz.size(); k++)
+        den[k] = Fr::sub(Fr::mul(Fr::pow_u64(domain.group_gen_inv, nz[k]), point), Fr::one());
+    host_batch_inverse(den);
+    Fr result = Fr::zero();
+    for (size_t k = 0; k < nz.size(); k++) result = Fr::add(result, Fr::mul(den[k], evaluations[nz[k]]));
+    return Fr::mul(result, numerator);
+}
+
+// evaluate_all_lagrange_coefficients(tau)[0] (fft/domain.rs:200-246)
+static Fr first_lagrange_coefficient(const Domain &d, const Fr &tau) {
+    Fr t_size = Fr::pow_u64(tau, d.size);
+    if (t_size == Fr::one()) return tau == Fr::one() ? Fr::one() : Fr::zero();
+    Fr l = Fr::mul(Fr::sub(t_size, Fr::one()), d.size_inv);
+    return Fr::mul(l, Fr::inv(Fr::sub(tau, Fr::one())));
+}
+
+int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host, size_t n_pi, const uint64_t *blinders14,
+                  ProofOut &out, ProveTimings *timings) {
+    ZK_REQUIRE(loaded(), ZKGPU_ERR_NOT_LOADED, "prove: no prover key loaded");
+    ZK_REQUIRE(wires_host != nullptr && blinders14 != nullptr, ZKGPU_ERR_INVALID_ARG, "prove: null input");
+    typedef std::chrono::steady_clock clk;
+    auto t_start = clk::now();
+    auto lap = [&](int slot, clk::time_point &since) {
+        if (!timings) return;
+        ZK_HIP(hipStreamSynchronize(stream_));
+        auto now = clk::now();
+        timings->ms[slot] = std::chrono::duration<float, std::milli>(now - since).count();
+        since = now;
+    };
+    auto t_phase = t_start;
+
+    const size_t n = n_, N8 = 8 * n, cap = n + 8;
+    const Domain domain = Domain::make(constraints_);  // prover.rs:224
+    ZK_REQUIRE(domain.size == n, ZKGPU_ERR_INVALID_ARG, "prove: constraints do not match the loaded key size");
+    Fr bl[14];
+    for (int i = 0; i < 14; i++) bl[i] = fr_from_words(blinders14 + 4 * i);
+    std::vector<Fr> public_inputs(n_pi);
+    for (size_t i = 0; i < n_pi; i++) public_inputs[i] = fr_from_words(public_inputs_host + 4 * i);
+
+    // per-proof device memory
+    //   wires 4n | a b c d z polys 5*cap | z evals n | pi n | t 8n | t_low t_mid t_high 3*cap | r, agg, witness 3*(5n) | evals 16
+    const size_t lin_cap = 5 * n + 16;
+    work_.reserve((4 * n + 5 * cap + 2 * n + N8 + 3 * cap + 3 * lin_cap + 64) * sizeof(Fr));
+    Fr *w = work_.as<Fr>();
+    Fr *wires = w;
+    Fr *p_a = wires + 4 * n, *p_b = p_a + cap, *p_c = p_b + cap, *p_d = p_c + cap, *p_z = p_d + cap;
+    Fr *z_evals = p_z + cap;
+    Fr *p_pi = z_evals + n;
+    Fr *t = p_pi + n;
+    Fr *t_low = t + N8, *t_mid = t_low + cap, *t_high = t_mid + cap;
+    Fr *r_poly = t_high + cap, *agg = r_poly + lin_cap, *wit = agg + lin_cap;
+    Fr *ev_dev = wit + lin_cap;
+
+    // transcript.rs:51-65 + widget.rs:199-228 (seed_transcript; "s_sigma_4" carries s_sigma_1, as in the reference)
+    PlonkTranscript tr(label_);
+    tr.circuit_domain_sep(constraints_);
+    {
+        static const struct {
+            const char *label;
+            int sel;
+        } order[] = {{"q_m", Q_M},         {"q_l", Q_L},         {"q_r", Q_R},     {"q_o", Q_O},
+                     {"q_c", Q_C},         {"q_f", Q_F},         {"q_arith", Q_ARITH}, {"q_range", Q_RANGE},
+                     {"q_logic", Q_LOGIC}, {"q_variable_group_add", Q_VAR}, {"q_fixed_group_add", Q_FIXED},
+                     {"s_sigma_1", S1},    {"s_sigma_2", S2},    {"s_sigma_3", S3}, {"s_sigma_4", S1}};
+        for (auto &o : order) tr.append_commitment(o.label, sel_comms_[o.sel]);
+        tr.circuit_domain_sep(constraints_);
+    }
+    for (auto &pi : public_inputs) tr.append_scalar("pi", pi);  // prover.rs:236-238
+
+    // round 1: wire polynomials (prover.rs:240-269)
+    ZK_HIP(hipMemcpyAsync(wires, wires_host, 4 * n * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+    Fr *wp[4] = {p_a, p_b, p_c, p_d};
+    for (int k = 0; k < 4; k++) blind_poly(wires + k * n, 1, bl + 2 * k, wp[k]);
+    int rc;
+    for (int k = 0; k < 4; k++)
+        if ((rc = commit_dev(wp[k], n + 2, out.comms[k]))) return rc;
+    tr.append_commitment("a_comm", out.comms[0]);
+    tr.append_commitment("b_comm", out.comms[1]);
+    tr.append_commitment("c_comm", out.comms[2]);
+    tr.append_commitment("d_comm", out.comms[3]);
+    lap(0, t_phase);
+
+    // round 2: permutation accumulator (prover.rs:271-293)
+    const Fr beta = tr.challenge_scalar("beta");
+    tr.append_scalar("beta", beta);
+    const Fr gamma = tr.challenge_scalar("gamma");
+    {
+        const Fr *wv[4] = {wires, wires + n, wires + 2 * n, wires + 3 * n};
+        const Fr *sv[4] = {sigma_.as<Fr>(), sigma_.as<Fr>() + n, sigma_.as<Fr>() + 2 * n, sigma_.as<Fr>() + 3 * n};
+        poly_.permutation_z(wv, sv, beta, gamma, ntt_.roots_half(log_n_), (uint32_t)n, z_evals);
+    }
+    blind_poly(z_evals, 2, bl + 8, p_z);
+    if ((rc = commit_dev(p_z, n + 3, out.comms[4]))) return rc;
+    tr.append_commitment("z_comm", out.comms[4]);
+    lap(1, t_phase);
+
+    // round 3: quotient (prover.rs:295-361)
+    const Fr alpha = tr.challenge_scalar("alpha");
+    const Fr range_ch = tr.challenge_scalar("range separation challenge");
+    const Fr logic_ch = tr.challenge_scalar("logic separation challenge");
+    const Fr fixed_ch = tr.challenge_scalar("fixed base separation challenge");
+    const Fr var_ch = tr.challenge_scalar("variable base separation challenge");
+    {
+        // composer.rs:1001-1014 dense public inputs, then ifft (prover.rs:305-306)
+        std::vector<Fr> dense(n, Fr::zero());
+        for (size_t i = 0; i < pi_indexes_.size() && i < n_pi; i++)
+            if (pi_indexes_[i] < n) dense[pi_indexes_[i]] = public_inputs[i];
+        ZK_HIP(hipMemcpyAsync(p_pi, dense.data(), n * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+        ZK_HIP(hipStreamSynchronize(stream_));
+        ntt_.transform(NTT_IFFT, p_pi, n, p_pi, log_n_);
+    }
+    const Fr ch7[7] = {alpha, beta, gamma, range_ch, logic_ch, fixed_ch, var_ch};
+    const uint64_t wl[4] = {n + 2, n + 2, n + 2, n + 2};
+    const uint64_t t_len = quotient(p_z, n + 3, wp, wl, p_pi, n, ch7, t);
+    lap(2, t_phase);
+    // prover.rs:327-351: the reference slices t[3n..] and indexes t_fourth[0]; both panic when t is shorter
+    if (t_len < 3 * n + 1) return ZKGPU_ERR_QUOTIENT_SHAPE;
+    const uint64_t t4_len = t_len - 3 * n;
+    ZK_HIP(hipMemcpyAsync(t_low, t, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream_));
+    ZK_HIP(hipMemcpyAsync(t_mid, t + n, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream_));
+    ZK_HIP(hipMemcpyAsync(t_high, t + 2 * n, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream_));
+    Fr *t_fourth = t + 3 * n;
+    {
+        const Fr b12 = bl[11], b13 = bl[12], b14 = bl[13];
+        uint64_t i1[1] = {n};
+        bool set1[1] = {false};
+        poly_.patch(t_low, i1, &b12, set1, 1);  // t_low.push(b_12)
+        uint64_t i2[2] = {0, n};
+        Fr v2[2] = {b12, b13};
+        bool s2[2] = {true, false};
+        poly_.patch(t_mid, i2, v2, s2, 2);  // t_mid[0] -= b_12 ; push(b_13)
+        Fr v3[2] = {b13, b14};
+        poly_.patch(t_high, i2, v3, s2, 2);  // t_high[0] -= b_13 ; push(b_14)
+        uint64_t i4[1] = {0};
+        bool s4[1] = {true};
+        poly_.patch(t_fourth, i4, &b14, s4, 1);  // t_fourth[0] -= b_14
+    }
+    if ((rc = commit_dev(t_low, n + 1, out.comms[5]))) return rc;
+    if ((rc = commit_dev(t_mid, n + 1, out.comms[6]))) return rc;
+    if ((rc = commit_dev(t_high, n + 1, out.comms[7]))) return rc;
+    if ((rc = commit_dev(t_fourth, t4_len, out.comms[8]))) return rc;
+    tr.append_commitment("t_low_comm", out.comms[5]);
+    tr.append_commitment("t_mid_comm", out.comms[6]);
+    tr.append_commitment("t_high_comm", out.comms[7]);
+    tr.append_commitment("t_fourth_comm", out.comms[8]);
+    lap(3, t_phase);
+
+    // round 4: evaluations (prover.rs:363-437)
+    const Fr z_ch = tr.challenge_scalar("z_challenge");
+    const Fr z_w = Fr::mul(z_ch, domain.group_gen);
+    enum { A, B, C, D, AW, BW, DW, QARITH, QC, QL, QR, SG1, SG2, SG3, ZE };
+    {
+        EvalJob jobs[15];
+        auto job = [&](int slot, const Fr *p, uint64_t len, const Fr &x) {
+            jobs[slot].coeffs = p;
+            jobs[slot].len = len;
+            jobs[slot].x = x;
+        };
+        job(A, p_a, n + 2, z_ch);
+        job(B, p_b, n + 2, z_ch);
+        job(C, p_c, n + 2, z_ch);
+        job(D, p_d, n + 2, z_ch);
+        job(AW, p_a, n + 2, z_w);
+        job(BW, p_b, n + 2, z_w);
+        job(DW, p_d, n + 2, z_w);
+        job(QARITH, key_poly(Q_ARITH), n, z_ch);
+        job(QC, key_poly(Q_C), n, z_ch);
+        job(QL, key_poly(Q_L), n, z_ch);
+        job(QR, key_poly(Q_R), n, z_ch);
+        job(SG1, key_poly(S1), n, z_ch);
+        job(SG2, key_poly(S2), n, z_ch);
+        job(SG3, key_poly(S3), n, z_ch);
+        job(ZE, p_z, n + 3, z_w);
+        poly_.evaluate(jobs, 15, ev_dev);
+        ZK_HIP(hipMemcpyAsync(out.evals, ev_dev, 15 * sizeof(Fr), hipMemcpyDeviceToHost, stream_));
+        ZK_HIP(hipStreamSynchronize(stream_));
+    }
+    const Fr *e = out.evals;
+    tr.append_scalar("a_eval", e[A]);
+    tr.append_scalar("b_eval", e[B]);
+    tr.append_scalar("c_eval", e[C]);
+    tr.append_scalar("d_eval", e[D]);
+    tr.append_scalar("s_sigma_1_eval", e[SG1]);
+    tr.append_scalar("s_sigma_2_eval", e[SG2]);
+    tr.append_scalar("s_sigma_3_eval", e[SG3]);
+    tr.append_scalar("z_eval", e[ZE]);
+    tr.append_scalar("a_w_eval", e[AW]);
+    tr.append_scalar("b_w_eval", e[BW]);
+    tr.append_scalar("d_w_eval", e[DW]);
+    tr.append_scalar("q_arith_eval", e[QARITH]);
+    tr.append_scalar("q_c_eval", e[QC]);
+    tr.append_scalar("q_l_eval", e[QL]);
+    tr.append_scalar("q_r_eval", e[QR]);
+    lap(4, t_phase);
+
+    // round 5: linearization (linearization_poly.rs:146-272) and openings (prover.rs:439-487)
+    const Fr v_ch = tr.challenge_scalar("v_challenge");
+    uint64_t r_len;
+    {
+        typedef InlineMul M;
+        LinArgs L;
+        int k = 0;
+        auto term = [&](const Fr *p, uint64_t len, const Fr &s) {
+            L.t[k].coeffs = p;
+            L.t[k].len = len;
+            L.t[k].scalar = s;
+            k++;
+        };
+        // arithmetic/proverkey.rs:75-107
+        const Fr qa = e[QARITH];
+        term(key_poly(Q_M), n, Fr::mul(Fr::mul(e[A], e[B]), qa));
+        term(key_poly(Q_L), n, Fr::mul(e[A], qa));
+        term(key_poly(Q_R), n, Fr::mul(e[B], qa));
+        term(key_poly(Q_O), n, Fr::mul(e[C], qa));
+        term(key_poly(Q_F), n, Fr::mul(e[D], qa));
+        term(key_poly(Q_C), n, qa);
+        // range / logic / fixed-base / curve-addition compute_linearization
+        term(key_poly(Q_RANGE), n, Fr::mul(w_range_identity<M>(range_ch, e[A], e[B], e[C], e[D], e[DW]), range_ch));
+        term(key_poly(Q_LOGIC), n,
+             Fr::mul(w_logic_identity<M>(logic_ch, e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW], e[QC]), logic_ch));
+        term(key_poly(Q_FIXED), n,
+             Fr::mul(w_fixed_base_identity<M>(fixed_ch, e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW], e[QL], e[QR], e[QC]),
+                     fixed_ch));
+        term(key_poly(Q_VAR), n, Fr::mul(w_curve_add_identity<M>(var_ch, e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW]), var_ch));
+        // permutation/proverkey.rs:121-245
+        const Fr beta_z = Fr::mul(beta, z_ch);
+        Fr acc = Fr::add(Fr::add(e[A], beta_z), gamma);
+        acc = Fr::mul(acc, Fr::add(Fr::add(e[B], mul_small<7>(beta_z)), gamma));
+        acc = Fr::mul(acc, Fr::add(Fr::add(e[C], mul_small<13>(beta_z)), gamma));
+        acc = Fr::mul(acc, Fr::add(Fr::add(e[D], mul_small<17>(beta_z)), gamma));
+        acc = Fr::mul(acc, alpha);
+        Fr cacc = Fr::add(Fr::add(e[A], Fr::mul(beta, e[SG1])), gamma);
+        cacc = Fr::mul(cacc, Fr::add(Fr::add(e[B], Fr::mul(beta, e[SG2])), gamma));
+        cacc = Fr::mul(cacc, Fr::add(Fr::add(e[C], Fr::mul(beta, e[SG3])), gamma));
+        cacc = Fr::mul(cacc, Fr::mul(beta, e[ZE]));
+        cacc = Fr::mul(cacc, alpha);
+        // EvaluationDomain::new(z_poly.degree() - 2) (permutation/proverkey.rs:156)
+        const uint64_t z_eff = poly_.length_without_leading_zeros(p_z, n + 3);
+        const uint64_t z_deg = z_eff ? z_eff - 1 : 0;
+        const Domain dz = Domain::make(z_deg >= 2 ? z_deg - 2 : 0);
+        const Fr l1_z = first_lagrange_coefficient(dz, z_ch);
+        term(p_z, n + 3, Fr::add(acc, Fr::mul(l1_z, Fr::sqr(alpha))));
+        term(key_poly(S4), n, Fr::neg(cacc));
+        // linearization_poly.rs:211-228
+        const Fr z_n = Fr::pow_u64(z_ch, n), z_2n = Fr::pow_u64(z_ch, 2 * n), z_3n = Fr::pow_u64(z_ch, 3 * n);
+        const Fr zh = Fr::neg(Fr::sub(z_n, Fr::one()));
+        term(t_low, n + 1, zh);
+        term(t_mid, n + 1, Fr::mul(z_n, zh));
+        term(t_high, n + 1, Fr::mul(z_2n, zh));
+        term(t_fourth, t4_len, Fr::mul(z_3n, zh));
+        L.n_terms = k;
+        // linearization_poly.rs:187-190 — the reference passes the SPARSE public-input list here
+        L.constant = barycentric_eval(public_inputs, z_ch, domain);
+        r_len = n + 3;
+        if (t4_len > r_len) r_len = t4_len;
+        ZK_REQUIRE(r_len <= lin_cap, ZKGPU_ERR_DEGREE_LARGE, "PolynomialDegreeTooLarge");
+        L.out = r_poly;
+        L.out_len = r_len;
+        poly_.linear_combination(L);
+    }
+    lap(5, t_phase);
+    {
+        // compute_aggregate_witness (kzg10/key.rs:131-146) at z with powers of v
+        LinArgs L;
+        const Fr *ps[8] = {r_poly, p_a, p_b, p_c, p_d, key_poly(S1), key_poly(S2), key_poly(S3)};
+        const uint64_t ls[8] = {r_len, n + 2, n + 2, n + 2, n + 2, n, n, n};
+        Fr pw = Fr::one();
+        uint64_t len = 0;
+        for (int k = 0; k < 8; k++) {
+            L.t[k].coeffs = ps[k];
+            L.t[k].len = ls[k];
+            L.t[k].scalar = pw;
+            pw = Fr::mul(pw, v_ch);
+            if (ls[k] > len) len = ls[k];
+        }
+        L.n_terms = 8;
+        L.constant = Fr::zero();
+        L.out = agg;
+        L.out_len = len;
+        poly_.linear_combination(L);
+        poly_.ruffini(agg, len, z_ch, wit);
+        if ((rc = commit_dev(wit, len - 1, out.comms[9]))) return rc;
+    }
+    const Fr v_w_ch = tr.challenge_scalar("v_w_challenge");
+    {
+        LinArgs L;
+        const Fr *ps[4] = {p_z, p_a, p_b, p_d};
+        const uint64_t ls[4] = {n + 3, n + 2, n + 2, n + 2};
+        Fr pw = Fr::one();
+        for (int k = 0; k < 4; k++) {
+            L.t[k].coeffs = ps[k];
+            L.t[k].len = ls[k];
+            L.t[k].scalar = pw;
+            pw = Fr::mul(pw, v_w_ch);
+        }
+        L.n_terms = 4;
+        L.constant = Fr::zero();
+        L.out = agg;
+        L.out_len = n + 3;
+        poly_.linear_combination(L);
+        poly_.ruffini(agg, n + 3, z_w, wit);
+        if ((rc = commit_dev(wit, n + 2, out.comms[10]))) return rc;
+    }
+    lap(6, t_phase);
+    const Fr chs[10] = {beta, gamma, alpha, range_ch, logic_ch, fixed_ch, var_ch, z_ch, v_ch, v_w_ch};
+    for (int i = 0; i < 10; i++) out.challenges[i] = chs[i];
+    if (timings) timings->ms[7] = std::chrono::duration<float, std::milli>(clk::now() - t_start).count();
+    return 0;
+}
+
+}  // namespace zk

@@ -1,0 +1,85 @@
+// GPU-resident restatement of the reference's prover orchestration: Compiler::preprocess
+// (plonk/src/compiler.rs:78-390) builds the device-resident ProverKey, Prover::prove
+// (plonk/src/compiler/prover.rs:210-509) runs the five rounds with the transcript, blinders and the 15 scalar
+// evaluations on the host and every polynomial on the device.
+#pragma once
+#include "common.hpp"
+#include "g1.cuh"
+#include "msm.hpp"
+#include "ntt.hpp"
+#include "poly.hpp"
+#include "transcript.hpp"
+#include <string>
+#include <vector>
+
+namespace zk {
+
+struct AffineOut {
+    Fq x, y;
+    bool infinity;
+};
+
+struct ProofOut {
+    AffineOut comms[11];  // a b c d z t_low t_mid t_high t_fourth w_z w_zw   (proof_system/proof.rs:29-65)
+    Fr evals[15];         // ProofEvaluations field order (linearization_poly.rs:29-74)
+    Fr challenges[10];    // beta gamma alpha range logic fixed var z v v_w
+};
+
+struct ProveTimings {
+    float ms[8];  // wire commits, permutation, quotient, quotient commits, evaluations, linearization, openings, total
+};
+
+class Prover {
+   public:
+    Prover(hipStream_t s, NttEngine &ntt, MsmEngine &msm, PolyEngine &poly) : stream_(s), ntt_(ntt), msm_(msm), poly_(poly) {}
+    ~Prover();
+
+    // Compiler::preprocess for a circuit given by its gate-wise selector values: selector_evals holds N_SEL x n
+    // Fr elements in Sel order (S1..S4 = the sigma values of build_permutation_lagrange_mapping,
+    // composer/permutation.rs:111-141).  Requires the SRS to be loaded.
+    void load_key(uint32_t n, uint64_t constraints, const uint64_t *selector_evals_host, const std::string &label,
+                  const uint64_t *pi_indexes, size_t n_pi);
+    bool loaded() const { return n_ != 0; }
+    uint32_t n() const { return n_; }
+    const AffineOut *selector_comms() const { return sel_comms_; }
+    // device pointers to the key (for the piecewise entry points and tests)
+    const Fr *key_poly(int k) const { return reinterpret_cast<const Fr *>(polys_.p) + (size_t)k * n_; }
+    const Fr *key_eval8n(int k) const;  // k < N_SEL selectors, N_SEL linear evaluations, N_SEL + 1 L1
+
+    // build_quotient_polynomial (quotient_poly.rs:15-100) on device polynomials; t_out must hold 8n elements.
+    // Returns the coefficient count after truncating leading zeros.
+    uint64_t quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4], const uint64_t wire_len[4], const Fr *pi,
+                      uint64_t pi_len, const Fr challenges7[7], Fr *t_out);
+
+    // Prover::prove.  wires_host: 4 x n values; blinders: 14 scalars in the reference's draw order.
+    // Returns 0 or a ZKGPU_ERR_* code for the reference's error paths.
+    int prove(const uint64_t *wires_host, const uint64_t *public_inputs_host, size_t n_pi, const uint64_t *blinders14,
+              ProofOut &out, ProveTimings *timings);
+
+    size_t device_bytes() const;
+
+   private:
+    // CommitKey::commit (kzg10/key.rs:108-129) of a device polynomial
+    int commit_dev(const Fr *coeffs, uint64_t len, AffineOut &out);
+    void blind_poly(const Fr *evals_dev, int hiding_degree, const Fr *blinders, Fr *out_dev);
+
+    hipStream_t stream_;
+    NttEngine &ntt_;
+    MsmEngine &msm_;
+    PolyEngine &poly_;
+    uint32_t n_ = 0, log_n_ = 0;
+    uint64_t constraints_ = 0;
+    std::string label_;
+    std::vector<uint64_t> pi_indexes_;
+    uint64_t poly_len_[N_SEL] = {0};
+    uint32_t widgets_ = 0;
+    Fr vh_inv_[8];
+    AffineOut sel_comms_[N_SEL];
+    DevBuf polys_;   // N_SEL x n coefficients
+    DevBuf evals_;   // (N_SEL + 2) x 8n: selector coset evaluations, X on the coset, L1 on the coset
+    DevBuf sigma_;   // 4 x n sigma values (their FFT is what compute_permutation_vec recomputes)
+    DevBuf work_;    // per-proof buffers
+    DevBuf small_;   // 15 evaluations etc.
+};
+
+}  // namespace zk

@@ -155,7 +155,7 @@ int zkgpu_poly_eval(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, const ui
 int zkgpu_poly_ruffini(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, const uint64_t root[4], uint64_t *out);
 
 /* Prover::prove (plonk/src/compiler/prover.rs:210-509) for the loaded key.  `wires` holds the 4 x n gate-wise
- * values a, b, c, d; `public_inputs` the n_pi public input values in index order; `blinders14` the 14 scalars
+ * values a, b, c, d (host memory, or a device pointer when the witness is already in HBM); `public_inputs` the n_pi public input values in index order; `blinders14` the 14 scalars
  * the reference draws from its RNG, in draw order a(2) b(2) c(2) d(2) z(3) b12 b13 b14.  Outputs: the 11
  * commitments in the order of Proof (a b c d z t_low t_mid t_high t_fourth w_z w_zw), the 15 evaluations in
  * ProofEvaluations field order, the ten challenges (beta gamma alpha range logic fixed var z v v_w) and,

@@ -272,8 +272,13 @@ class Prover:
         return out[:t_len.value].copy()
 
     def prove(self, wires, public_inputs, blinders14, timings=False):
-        w = _np_u64(wires, 4)
-        assert w.shape[0] == 4 * self.n
+        if _is_torch(wires):
+            assert wires.is_cuda and wires.is_contiguous() and wires.numel() == 16 * self.n
+            w_ptr = wires.data_ptr()
+        else:
+            w = _np_u64(wires, 4)
+            assert w.shape[0] == 4 * self.n
+            w_ptr = w.ctypes.data
         pi = _np_u64(public_inputs, 4)
         bl = _np_u64(blinders14, 4)
         assert bl.shape[0] == 14
@@ -282,7 +287,7 @@ class Prover:
         evals = np.zeros((15, 4), dtype=np.uint64)
         chal = np.zeros((10, 4), dtype=np.uint64)
         tm = (C.c_float * 8)()
-        self.ctx._check(self.ctx._lib.zkgpu_prove(self.ctx._h, w.ctypes.data, pi.ctypes.data if pi.size else None,
+        self.ctx._check(self.ctx._lib.zkgpu_prove(self.ctx._h, w_ptr, pi.ctypes.data if pi.size else None,
                                                   pi.shape[0], bl.ctypes.data, comms.ctypes.data, inf.ctypes.data,
                                                   evals.ctypes.data, chal.ctypes.data, tm if timings else None))
         out = dict(comms=comms, comms_inf=inf, evals=evals, challenges=chal)

@@ -305,7 +305,8 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     for (auto &pi : public_inputs) tr.append_scalar("pi", pi);  // prover.rs:236-238
 
     // round 1: wire polynomials (prover.rs:240-269)
-    ZK_HIP(hipMemcpyAsync(wires, wires_host, 4 * n * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+    // hipMemcpyDefault: the caller's pointer may be host memory or already resident in HBM
+    ZK_HIP(hipMemcpyAsync(wires, wires_host, 4 * n * sizeof(Fr), hipMemcpyDefault, stream_));
     Fr *wp[4] = {p_a, p_b, p_c, p_d};
     for (int k = 0; k < 4; k++) blind_poly(wires + k * n, 1, bl + 2 * k, wp[k]);
     int rc;

@@ -137,7 +137,7 @@ def run_ntt(args, rank, world, local, device):
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                            "avg_launch_ms": round(launch_ms, 4),
                            "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
-                           "note": "VALU-bound (one Fr product per butterfly, ~300 VALU instructions each); see DESIGN.md"}
+                           "note": "VALU-bound (one Fr product per butterfly, ~300 VALU instructions each)"}
         out["per_transform_ms"] = {}
         for mode, lg, name in ((0, LOG_N, "fft_2^20"), (1, LOG_N, "ifft_2^20"), (2, LOG_N + 3, "coset_fft_2^23"),
                                (3, LOG_N + 3, "coset_ifft_2^23")):

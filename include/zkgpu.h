@@ -1,8 +1,8 @@
 /* zkgpu — C boundary of the MI355X PLONK prover core.
  *
  * The reference (zk590/zkvm, a Rust workspace) has no FFI for this path: its hot functions are private Rust
- * methods.  Each entry point below names the reference function it replaces; INTEGRATION.md shows the
- * `extern "C"` block and the call sites a maintainer adds to the `plonk` crate.
+ * methods.  Each entry point below names the reference function it replaces; rust/zkgpu-sys holds the
+ * `extern "C"` block a maintainer adds to the `plonk` crate to bind them.
  *
  * Data formats (identical to the reference's in-memory representations, so no conversion is needed):
  *   Fr element      4 x uint64_t little-endian limbs, Montgomery form, canonical (< r)   = Scalar.0

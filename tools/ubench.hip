@@ -1,4 +1,4 @@
-// Micro-benchmarks behind the VALU ceilings quoted in DESIGN.md: issue cost of the integer / f64 instructions
+// Micro-benchmarks of the VALU ceilings that bound the field arithmetic: issue cost of the integer / f64 instructions
 // the field arithmetic is made of, and whole-chip throughput of the Fr and Fq Montgomery products.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I zkvm_amd/csrc tools/ubench.hip -o tools/ubench && tools/ubench
 #include <hip/hip_runtime.h>

@@ -189,24 +189,16 @@ def run_msm(args, rank, world, local, device):
     import torch
     import zkvm_amd
     ctx = zkvm_amd.Context(local)
+    from zkvm_amd import sharding
     n_total = 1 << MSM_LOG
-    shard = n_total // world
+    base, shard = sharding.shard_range(n_total, rank, world)
     pts = synthetic_points(ctx, n_total, device)
-    ctx.srs_load(pts[rank * shard:(rank + 1) * shard].contiguous())
+    ctx.srs_load(pts[base:base + shard].contiguous())
     del pts
-    scalars = to_dev(random_fr(n_total, 3)[rank * shard:(rank + 1) * shard], device)   # seed 3: uniform scalars
+    scalars = to_dev(random_fr(n_total, 3)[base:base + shard], device)   # seed 3: uniform scalars
 
     def step():
-        part = ctx.msm_partial(scalars, 0)
-        if world > 1:
-            import torch.distributed as dist
-            mine = torch.from_numpy(part.view(np.int64)).to(device)
-            gathered = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(gathered, mine)
-            parts = np.stack([g.cpu().numpy().view(np.uint64) for g in gathered])
-        else:
-            parts = part.reshape(1, 18)
-        return zkvm_amd.g1_sum_to_affine(parts)
+        return sharding.sharded_msm(ctx, scalars, device)
 
     for _ in range(max(args.warmup, 1)):
         step()

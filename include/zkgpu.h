@@ -93,6 +93,11 @@ int zkgpu_srs_load(zkgpu_ctx *ctx, const uint64_t *xy, const uint8_t *infinity, 
 /* As above from a device buffer of n_points x 96 bytes (copied). */
 int zkgpu_srs_load_dev(zkgpu_ctx *ctx, const void *xy_dev, size_t n_points);
 
+/* Tuning knobs of the bucket method, for experiments and tests: the signed-digit window width used by the NEXT
+ * zkgpu_srs_load* (4..22, 0 = chosen from the table size) and the log2 segment width of the bucket reduction
+ * (1..6, 0 = default).  Results do not depend on them. */
+int zkgpu_msm_set_params(zkgpu_ctx *ctx, uint32_t window_bits, uint32_t segment_bits);
+
 /* msm_variable_base(&powers_of_g, scalars) followed by Commitment::from(G1Projective)
  * (coset-bls12_381/src/coset/multiscalar_mul.rs:143-220, kzg10/commitment.rs:34-38): the affine sum of
  * scalars[i] * powers_of_g[i] over i < min(n, n_points), as the reference's zip truncates.  `scalars` is a HOST

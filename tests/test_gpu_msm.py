@@ -134,3 +134,28 @@ def test_msm_2_16_device_scalars_and_sharding(ctx, orc):
     p1 = ctx.msm_partial(sd[half:].contiguous(), half)
     xy, inf = zkvm_amd.g1_sum_to_affine(np.stack([p0, p1]))
     assert inf == want_inf and np.array_equal(xy, want_xy)
+
+
+@pytest.mark.parametrize("window_bits,segment_bits", [(4, 1), (5, 3), (9, 2), (13, 4), (16, 3), (18, 6), (21, 5), (22, 4)])
+def test_msm_window_and_segment_widths(ctx, orc, window_bits, segment_bits):
+    """The table of window multiples and the bucket reduction are exact for every window width (1 to 64 levels,
+    8 to 2^20 buckets) and segment width; partial ranges index the table with their base."""
+    n = 700
+    pts, _ = orc.g1_multiples_of_generator(2, n)
+    sc = M.random_fr_mont(n, 900 + window_bits)
+    sc[0] = 0
+    sc[1] = M.fr_to_mont(1)
+    sc[2] = M.fr_to_mont(M.R_MOD - 1)
+    sc[3:40] = sc[3]                      # one oversized bucket per level
+    try:
+        ctx.msm_set_params(window_bits, segment_bits)
+        check(ctx, orc, pts, sc)
+        import torch
+        import zkvm_amd
+        sd = torch.from_numpy(sc[100:300].view(np.int64)).cuda()
+        part = ctx.msm_partial(sd, 100)
+        xy, inf = zkvm_amd.g1_sum_to_affine(part.reshape(1, 18))
+        want_xy, want_inf = oracle_affine(orc, pts[100:300], sc[100:300])
+        assert inf == want_inf and np.array_equal(xy, want_xy)
+    finally:
+        ctx.msm_set_params(0, 0)

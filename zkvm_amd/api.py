@@ -118,6 +118,10 @@ class Context:
         self._check(self._lib.zkgpu_srs_load(self._h, pts.ctypes.data, inf.ctypes.data if inf is not None else None,
                                              pts.shape[0]))
 
+    def msm_set_params(self, window_bits=0, segment_bits=0):
+        """Tuning knobs (0 = automatic); window_bits applies to the next srs_load."""
+        self._check(self._lib.zkgpu_msm_set_params(self._h, int(window_bits), int(segment_bits)))
+
     def msm(self, scalars):
         """-> (xy limbs (12,), infinity flag): affine sum_i scalars[i] * SRS[i]."""
         out = np.zeros(12, dtype=np.uint64)

@@ -200,6 +200,16 @@ int zkgpu_msm_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, uint64_t ou
     });
 }
 
+int zkgpu_msm_set_params(zkgpu_ctx *ctx, uint32_t window_bits, uint32_t segment_bits) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(window_bits == 0 || (window_bits >= 4 && window_bits <= 22), ZKGPU_ERR_INVALID_ARG,
+                   "msm_set_params: window_bits must be 0 or within 4..22");
+        ZK_REQUIRE(segment_bits <= 6, ZKGPU_ERR_INVALID_ARG, "msm_set_params: segment_bits must be 0 or within 1..6");
+        ctx->msm->set_window_override(window_bits);
+        ctx->msm->set_segment_bits(segment_bits ? segment_bits : 3);
+    });
+}
+
 int zkgpu_msm(zkgpu_ctx *ctx, const uint64_t *scalars, size_t n, uint64_t out_xy[12], uint8_t *out_infinity) {
     return guarded(ctx, [&] {
         ZK_REQUIRE(scalars != nullptr || n == 0, ZKGPU_ERR_INVALID_ARG, "msm: null scalars");

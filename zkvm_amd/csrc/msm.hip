@@ -1,17 +1,23 @@
-// Pippenger bucket MSM for gfx950 with signed window digits and a counting sort of (window, bucket) keys.
+// Pippenger bucket MSM for gfx950 over a resident point table with precomputed window multiples.
 //
-//   1. digits    every scalar leaves Montgomery form and is cut into K signed digits of c bits
-//                (|digit| <= 2^(c-1)), one plane of digits per window;
-//   2. sort      counting sort by (window, bucket) with per-workgroup histograms in LDS (no global atomics):
-//                count pass, exclusive scan = bucket start offsets, scatter pass writing point indices (with
-//                the digit's sign in bit 31) bucket by bucket; oversized buckets are cut into fixed-size
+// The SRS is loaded once and reused by every commitment, and HBM is plentiful, so loading it also stores
+// 2^(c w) * P_i for every window w (K = floor(255/c) + 1 levels, affine).  A scalar's K signed c-bit digits then
+// all select entries of ONE bucket set: sum_i s_i P_i = sum_b (b+1) * sum_{(i,w): |digit_w(s_i)| = b+1} +-T[w][i].
+// There is a single bucket reduction per MSM instead of one per window, and no doubling chain at the end.
+//
+//   1. digits    every scalar leaves Montgomery form and is cut into K signed digits (|digit| <= 2^(c-1));
+//   2. sort      counting sort of the n*K (entry, bucket) pairs with per-workgroup histograms in LDS (no global
+//                atomics): count pass, exclusive scan = bucket start offsets, scatter pass writing table indices
+//                (with the digit's sign in bit 31) bucket by bucket; oversized buckets are cut into fixed-size
 //                tasks so that no thread ever owns more than BIG_BUCKET additions;
 //   3. schedule  buckets are ordered by decreasing size so that the lanes of a wave carry equal work;
-//   4. accumulate one thread per bucket adds its points with the complete mixed addition; oversized
+//   4. accumulate one thread per bucket adds its entries with the complete mixed addition; oversized
 //                buckets are summed by whole workgroups (strided partial sums + LDS tree);
-//   5. reduce    sum_b (b+1) * bucket_b per window from segment-wise running sums, then a tree per window;
-//   6. the K window sums return to the host, which runs the Horner chain of doublings and the affine
-//                conversion — a strictly serial chain of ~255 point doublings that would occupy one lane.
+//   5. reduce    sum_b (b+1) * bucket_b: running sums over segments of L buckets give per-segment totals T_s and
+//                local weighted sums W_s; sum_s s*T_s is then taken bit by bit (Q_k = sum of the T_s whose index
+//                has bit k set), every sum a wide tree, because an EC addition has ~30 us of latency at low
+//                occupancy and depth, not work, is what this phase costs;
+//   6. the few group sums return to the host: total = sum W + L * sum_k 2^k Q_k + sum T, then to affine.
 // The reference's unsigned digits, window size and special cases for 0 and 1
 // (multiscalar_mul.rs:150-195) change only the order of group additions; the sum, and so the affine
 // commitment compared by the tests, is the same group element.
@@ -19,7 +25,8 @@
 
 namespace zk {
 
-static const uint32_t BIG_BUCKET = 256;   // buckets with more entries are processed by workgroups
+static const uint32_t BIG_BUCKET = 256;   // size classes of the schedule; buckets above BIG_BUCKET << shift entries are
+                                          // processed by workgroups (shift grows with the mean bucket size)
 static const uint32_t BIG_CHUNK = 4096;   // entries per workgroup task
 static const uint32_t SCAN_ITEMS = 1024;  // histogram entries scanned per block
 
@@ -93,33 +100,36 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const Fr *scalars, uint
     }
 }
 
-// Counting sort without global atomics.  Workgroup (s, r, w) owns slice s of the scalars, bucket range r of
-// window w, and a private histogram of that range in LDS.
-//   pass 0 (count):   part[(w * S + s) * B + bucket] = number of slice entries in the bucket
-//   pass 1 (scatter): part[...] holds the first output position for (w, s, bucket); entries are written there
+// Counting sort without global atomics over the flat list of n_items = n * K digits (item j = w * n + i).
+// Workgroup (s, r) owns slice s of the items, bucket range r, and a private histogram of that range in LDS.
+//   pass 0 (count):   part[s * B + bucket] = number of slice entries in the bucket
+//   pass 1 (scatter): part[...] holds the first output position for (s, bucket); the table index
+//                     w * stride + base + i of every entry is written there
 struct SortGeom {
-    uint32_t n, B, log_range, S, slice;  // slice = ceil(n / S)
+    uint32_t n_items, n, stride, base, B, log_range, S, slice;  // slice = ceil(n_items / S)
 };
 template <int PASS>
 __global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t *dig, SortGeom g, uint32_t *part, uint32_t *sorted) {
     extern __shared__ uint32_t hist[];
     const uint32_t range = 1u << g.log_range;
-    const uint32_t s = blockIdx.x, r = blockIdx.y, w = blockIdx.z;
-    uint32_t *mine = part + ((size_t)(w * g.S + s)) * g.B + ((size_t)r << g.log_range);
+    const uint32_t s = blockIdx.x, r = blockIdx.y;
+    uint32_t *mine = part + (size_t)s * g.B + ((size_t)r << g.log_range);
     for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) hist[t] = PASS ? mine[t] : 0u;
     __syncthreads();
     const uint32_t lo = s * g.slice;
     uint32_t hi = lo + g.slice;
-    if (hi > g.n) hi = g.n;
-    const uint32_t *d = dig + (size_t)w * g.n;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        uint32_t v = d[i];
+    if (hi > g.n_items || hi < lo) hi = g.n_items;
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+        uint32_t v = dig[j];
         uint32_t mag = v & 0x7fffffffu;
         if (!mag) continue;
         uint32_t b = mag - 1;
         if ((b >> g.log_range) != r) continue;
         uint32_t pos = atomicAdd(&hist[b & (range - 1)], 1u);
-        if (PASS) sorted[pos] = i | (v & 0x80000000u);
+        if (PASS) {
+            uint32_t w = j / g.n, i = j - w * g.n;
+            sorted[pos] = (w * g.stride + g.base + i) | (v & 0x80000000u);
+        }
     }
     if (!PASS) {
         __syncthreads();
@@ -127,21 +137,21 @@ __global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t *dig, Sor
     }
 }
 
-// counts[w * B + b] = sum over slices
-__global__ void __launch_bounds__(256) msm_totals_kernel(const uint32_t *part, uint32_t nb, uint32_t B, uint32_t S, uint32_t *counts) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nb) return;
-    uint32_t w = i / B, b = i - w * B, tot = 0;
-    for (uint32_t s = 0; s < S; s++) tot += part[((size_t)(w * S + s)) * B + b];
-    counts[i] = tot;
+// counts[b] = sum over slices
+__global__ void __launch_bounds__(256) msm_totals_kernel(const uint32_t *part, uint32_t B, uint32_t S, uint32_t *counts) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t tot = 0;
+    for (uint32_t s = 0; s < S; s++) tot += part[(size_t)s * B + b];
+    counts[b] = tot;
 }
-// part[...] <- first output position of every (window, slice, bucket)
-__global__ void __launch_bounds__(256) msm_cursors_kernel(uint32_t *part, const uint32_t *offsets, uint32_t nb, uint32_t B, uint32_t S) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nb) return;
-    uint32_t w = i / B, b = i - w * B, run = offsets[i];
+// part[...] <- first output position of every (slice, bucket)
+__global__ void __launch_bounds__(256) msm_cursors_kernel(uint32_t *part, const uint32_t *offsets, uint32_t B, uint32_t S) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t run = offsets[b];
     for (uint32_t s = 0; s < S; s++) {
-        size_t idx = ((size_t)(w * S + s)) * B + b;
+        size_t idx = (size_t)s * B + b;
         uint32_t t = part[idx];
         part[idx] = run;
         run += t;
@@ -206,14 +216,14 @@ __global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t *block_sums, u
 }
 
 __global__ void __launch_bounds__(256) scan_finish_kernel(const uint32_t *counts, uint32_t *offsets,
-                                                          const uint32_t *block_sums, uint32_t nb, MsmTask *tasks,
+                                                          const uint32_t *block_sums, uint32_t nb, uint32_t big, MsmTask *tasks,
                                                           uint32_t *task_count, uint32_t max_tasks) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
     uint32_t off = offsets[i] + block_sums[i / SCAN_ITEMS];
     offsets[i] = off;
     uint32_t cnt = counts[i];
-    if (cnt > BIG_BUCKET) {
+    if (cnt > big) {
         uint32_t nt = (cnt + BIG_CHUNK - 1) / BIG_CHUNK;
         uint32_t t0 = atomicAdd(task_count, nt);
         for (uint32_t k = 0; k < nt && t0 + k < max_tasks; k++) {
@@ -229,13 +239,13 @@ __global__ void __launch_bounds__(256) scan_finish_kernel(const uint32_t *counts
 
 // ---- bucket schedule --------------------------------------------------------------------------------------
 // Buckets are visited in order of decreasing size so that the 64 lanes of a wave own buckets of (nearly) equal
-// size.  Size classes: class 0 = BIG_BUCKET entries ... class BIG_BUCKET = empty; oversized buckets are left out
-// (they go through msm_big_*).  Two passes over the counts: class histogram, then placement.
+// size.  Size classes by count >> shift: class 0 = the largest ... class BIG_BUCKET = the smallest; oversized
+// buckets are left out (they go through msm_big_*).  Two passes over the counts: class histogram, then placement.
 static const uint32_t N_CLASSES = BIG_BUCKET + 1;
 
 template <int PASS>
-__global__ void __launch_bounds__(1024) msm_schedule_kernel(const uint32_t *counts, uint32_t nb, uint32_t *class_cursor,
-                                                            uint32_t *order) {
+__global__ void __launch_bounds__(1024) msm_schedule_kernel(const uint32_t *counts, uint32_t nb, uint32_t shift,
+                                                            uint32_t *class_cursor, uint32_t *order) {
     __shared__ uint32_t hist[N_CLASSES];
     __shared__ uint32_t base[N_CLASSES];
     for (uint32_t t = threadIdx.x; t < N_CLASSES; t += blockDim.x) hist[t] = 0;
@@ -244,8 +254,8 @@ __global__ void __launch_bounds__(1024) msm_schedule_kernel(const uint32_t *coun
     uint32_t cls = 0xffffffffu, rank = 0;
     if (i < nb) {
         uint32_t cnt = counts[i];
-        if (cnt <= BIG_BUCKET) {
-            cls = BIG_BUCKET - cnt;
+        if (cnt <= (BIG_BUCKET << shift)) {
+            cls = BIG_BUCKET - (cnt >> shift);
             rank = atomicAdd(&hist[cls], 1u);
         }
     }
@@ -306,10 +316,11 @@ __device__ __forceinline__ G1Proj lds_load_proj(const uint32_t *sh, uint32_t slo
     }
     return p;
 }
-// Sums the 256 per-thread points of a workgroup; the total is returned in thread 0.
-__device__ __forceinline__ G1Proj block_tree_sum(uint32_t *sh, G1Proj acc) {
+// Sums the per-thread points of the first 2 * first_stride threads of a workgroup (the rest must hold the
+// identity or be beyond the data); the total is returned in thread 0.
+__device__ __forceinline__ G1Proj block_tree_sum(uint32_t *sh, G1Proj acc, uint32_t first_stride = 128) {
     const uint32_t tid = threadIdx.x;
-    for (uint32_t stride = 128; stride >= 1; stride >>= 1) {
+    for (uint32_t stride = first_stride; stride >= 1; stride >>= 1) {
         if (tid >= stride && tid < 2 * stride) lds_store_proj(sh, tid - stride, acc);
         __syncthreads();
         if (tid < stride) acc = g1_add(acc, lds_load_proj(sh, tid));
@@ -318,7 +329,7 @@ __device__ __forceinline__ G1Proj block_tree_sum(uint32_t *sh, G1Proj acc) {
     return acc;
 }
 
-__global__ void __launch_bounds__(256) msm_big_partial_kernel(const G1Affine *points, const uint32_t *sorted,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_big_partial_kernel(const G1Affine *points, const uint32_t *sorted,
                                                               const MsmTask *tasks, const uint32_t *task_count,
                                                               uint32_t max_tasks, G1Proj *partials) {
     __shared__ uint32_t sh[128 * 36];
@@ -338,7 +349,7 @@ __global__ void __launch_bounds__(256) msm_big_partial_kernel(const G1Affine *po
 }
 
 // One workgroup per oversized bucket: strided sums of its task partials, then the LDS tree.
-__global__ void __launch_bounds__(256) msm_big_combine_kernel(const MsmTask *tasks, const uint32_t *task_count,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_big_combine_kernel(const MsmTask *tasks, const uint32_t *task_count,
                                                               uint32_t max_tasks, const G1Proj *partials, G1Proj *buckets) {
     __shared__ uint32_t sh[128 * 36];
     uint32_t n_tasks = *task_count;
@@ -356,32 +367,118 @@ __global__ void __launch_bounds__(256) msm_big_combine_kernel(const MsmTask *tas
 }
 
 // ---- bucket reduction -------------------------------------------------------------------------------------
-// One thread per (window, segment of `seg` buckets): sum_r (seg_base + r + 1) * bucket[seg_base + r].
-__global__ void __launch_bounds__(256) msm_segment_kernel(const G1Proj *buckets, uint32_t log_B, uint32_t log_seg,
-                                                          uint32_t n_threads, G1Proj *seg_out) {
+// Level 1: one thread per segment s of L = 2^log_seg buckets: T_s = sum_j bucket[sL + j] and
+// W_s = sum_j j * bucket[sL + j] by running sums from the top.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_segment_kernel(const G1Proj *buckets, uint32_t log_seg, uint32_t n_segments,
+                                                          G1Proj *t_out, G1Proj *w_out) {
     uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n_threads) return;
-    const uint32_t segs_per_window_log = log_B - log_seg;
-    const uint32_t w = gid >> segs_per_window_log, g = gid & ((1u << segs_per_window_log) - 1u);
+    if (gid >= n_segments) return;
     const uint32_t seg = 1u << log_seg;
-    const G1Proj *bp = buckets + ((size_t)w << log_B) + ((size_t)g << log_seg);
+    const G1Proj *bp = buckets + ((size_t)gid << log_seg);
     G1Proj run = G1Proj::identity(), acc = G1Proj::identity();
-    for (int r = (int)seg - 1; r >= 0; r--) {
+    for (int r = (int)seg - 1; r >= 1; r--) {
         run = g1_add(run, gload_proj(bp + r));
         acc = g1_add(acc, run);
     }
-    if (g) acc = g1_add(acc, g1_mul_small(run, g << log_seg));
-    gstore_proj(seg_out + gid, acc);
+    run = g1_add(run, gload_proj(bp));
+    gstore_proj(t_out + gid, run);
+    gstore_proj(w_out + gid, acc);
 }
 
-// One workgroup per window: sum of its segment results.
-__global__ void __launch_bounds__(256) msm_window_kernel(const G1Proj *seg_out, uint32_t segs_per_window, G1Proj *window_sums) {
+// Level 2: equally sized groups of n_segments / 2 elements each, so that every workgroup carries the same work:
+//   g < n_bits       the T_s with bit g of s set            (Q_g)
+//   g = n_bits       the T_s with the top bit of s clear    (with Q_top: the sum of all T_s)
+//   g = n_bits + 1/2 the lower / upper half of the W_s
+// With a single segment (n_bits = 0) there are two groups of one element: T_0 and W_0.
+// grid = (blocks per group, groups); each block leaves one partial sum.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_group_partial_kernel(const G1Proj *t_in, const G1Proj *w_in, uint32_t n_segments,
+                                                                uint32_t n_bits, G1Proj *partials) {
     __shared__ uint32_t sh[128 * 36];
-    const uint32_t w = blockIdx.x;
+    const uint32_t g = blockIdx.y;
+    const uint32_t count = n_bits ? (n_segments >> 1) : 1u;
+    const G1Proj *src = t_in;
+    uint32_t k = g, set = 1u, offset = 0;
+    if (n_bits == 0) {
+        if (g == 1) src = w_in;
+        k = 0xffffffffu;
+    } else if (g == n_bits) {
+        k = n_bits - 1;
+        set = 0;
+    } else if (g > n_bits) {
+        src = w_in;
+        k = 0xffffffffu;
+        offset = (g - n_bits - 1) * count;
+    }
     G1Proj acc = G1Proj::identity();
-    for (uint32_t k = threadIdx.x; k < segs_per_window; k += 256) acc = g1_add(acc, gload_proj(seg_out + (size_t)w * segs_per_window + k));
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < count; j += gridDim.x * 256) {
+        uint32_t e = j + offset;
+        if (k != 0xffffffffu) e = ((j >> k) << (k + 1)) | (set << k) | (j & ((1u << k) - 1u));   // j-th index with bit k set/clear
+        acc = g1_add(acc, gload_proj(src + e));
+    }
     acc = block_tree_sum(sh, acc);
-    if (threadIdx.x == 0) gstore_proj(window_sums + w, acc);
+    if (threadIdx.x == 0) gstore_proj(partials + (size_t)g * gridDim.x + blockIdx.x, acc);
+}
+
+// Level 3: one workgroup per group adds that group's partial sums.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_group_final_kernel(const G1Proj *partials, uint32_t per_group, G1Proj *out) {
+    __shared__ uint32_t sh[128 * 36];
+    const uint32_t g = blockIdx.x;
+    G1Proj acc = G1Proj::identity();
+    for (uint32_t k = threadIdx.x; k < per_group; k += 256) acc = g1_add(acc, gload_proj(partials + (size_t)g * per_group + k));
+    uint32_t first = 128;
+    while (first > 1 && first >= per_group) first >>= 1;   // threads >= per_group hold the identity
+    acc = block_tree_sum(sh, acc, first);
+    if (threadIdx.x == 0) gstore_proj(out + g, acc);
+}
+
+// ---- table of window multiples ----------------------------------------------------------------------------
+__device__ __forceinline__ void gstore_affine(G1Affine *p, const Fq &x, const Fq &y) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    gstore_fq(q, x);
+    gstore_fq(q + 3, y);
+}
+// Thread t extends point first + t: level w holds 2^(c w) * P in affine form.  The projective multiples are
+// written unnormalised first; their Z coordinates and running products go to scratch so that one inversion per
+// point converts all levels (Montgomery's trick along the levels).
+__global__ void __launch_bounds__(256) msm_table_kernel(G1Affine *table, uint32_t stride, uint32_t first, uint32_t count,
+                                                        uint32_t c, uint32_t K, Fq *z_scratch, Fq *prefix_scratch) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t i = first + t;
+    const G1Affine p = gload_affine(table + i);
+    if (p.is_identity()) {
+        for (uint32_t w = 1; w < K; w++) gstore_affine(table + (size_t)w * stride + i, Fq::zero(), Fq::zero());
+        return;
+    }
+    G1Proj q;
+    q.x = p.x;
+    q.y = p.y;
+    q.z = Fq::one();
+    Fq pre = Fq::one();
+    for (uint32_t w = 1; w < K; w++) {
+        for (uint32_t k = 0; k < c; k++) q = g1_double(q);
+        gstore_affine(table + (size_t)w * stride + i, q.x, q.y);
+        Fq z = q.z.is_zero() ? Fq::one() : q.z;   // cannot happen for points of prime order; keeps the product invertible
+        pre = Fq::mul(pre, z);
+        uint4 *zq = reinterpret_cast<uint4 *>(z_scratch + (size_t)(w - 1) * count + t);
+        uint4 *pq = reinterpret_cast<uint4 *>(prefix_scratch + (size_t)(w - 1) * count + t);
+        gstore_fq(zq, q.z);
+        gstore_fq(pq, pre);
+    }
+    Fq inv = Fq::inv(pre);
+    for (uint32_t w = K - 1; w >= 1; w--) {
+        Fq z = gload_fq(reinterpret_cast<const uint4 *>(z_scratch + (size_t)(w - 1) * count + t));
+        G1Affine *slot = table + (size_t)w * stride + i;
+        if (z.is_zero()) {
+            gstore_affine(slot, Fq::zero(), Fq::zero());
+            continue;
+        }
+        Fq zinv = inv;
+        if (w > 1) zinv = Fq::mul(inv, gload_fq(reinterpret_cast<const uint4 *>(prefix_scratch + (size_t)(w - 2) * count + t)));
+        inv = Fq::mul(inv, z);
+        G1Affine u = gload_affine(slot);
+        gstore_affine(slot, Fq::mul(u.x, zinv), Fq::mul(u.y, zinv));
+    }
 }
 
 // (0,0)-encode points flagged as infinity
@@ -396,19 +493,59 @@ __global__ void msm_mark_infinity_kernel(G1Affine *points, const uint8_t *inf, u
 // ---------------------------------------------------------------------------------------------------------
 MsmEngine::~MsmEngine() {
     DevBuf *all[] = {&points_, &counts_, &offsets_, &cursor_, &sorted_, &buckets_, &block_sums_, &tasks_, &partials_,
-                     &misc_,   &seg_,    &window_sums_, &order_, &digits_};
+                     &misc_,   &seg_,    &group_sums_, &order_, &digits_};
     for (DevBuf *b : all) b->release();
 }
 
 size_t MsmEngine::device_bytes() const {
     return points_.cap + counts_.cap + offsets_.cap + cursor_.cap + sorted_.cap + buckets_.cap + block_sums_.cap +
-           tasks_.cap + partials_.cap + misc_.cap + seg_.cap + window_sums_.cap + order_.cap + digits_.cap;
+           tasks_.cap + partials_.cap + misc_.cap + seg_.cap + group_sums_.cap + order_.cap + digits_.cap;
+}
+
+// Window width for a table of n points: minimises n * K * 11 products of accumulation plus ~30 products per
+// bucket of reduction; K = floor(255 / c) + 1 signed digits always cover a 255-bit scalar.  All levels share
+// one bucket set, so a short top window (255 - (K-1) c bits) piles its n digits onto few buckets, which then
+// go through the slower oversized-bucket path: such widths are charged for it.
+uint32_t MsmEngine::choose_window(size_t n) {
+    uint32_t best = 4;
+    double best_cost = 1e300;
+    for (uint32_t c = 4; c <= 22; c++) {
+        const uint32_t K = 255 / c + 1, top_bits = 255 - (K - 1) * c;
+        const double mean = (double)n * K / (double)(1u << (c - 1));
+        double cost = (double)n * K * 11.0 + (double)(1u << (c - 1)) * 30.0;
+        if (top_bits < c - 1 && (double)n / (double)(1u << top_bits) > 2.0 * mean + BIG_BUCKET) cost += (double)n * 11.0 * 4.0;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
+}
+
+void MsmEngine::build_table(size_t n) {
+    c_ = window_override_ ? window_override_ : choose_window(n);
+    K_ = 255 / c_ + 1;
+    ZK_REQUIRE((uint64_t)n * K_ < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "srs_load: table of window multiples exceeds 2^31 entries");
+    n_points_ = n;
+    if (n == 0 || K_ == 1) return;
+    const uint32_t chunk = n < (1u << 18) ? (uint32_t)n : (1u << 18);
+    misc_.reserve((size_t)2 * (K_ - 1) * chunk * sizeof(Fq));
+    Fq *z_scratch = misc_.as<Fq>(), *prefix_scratch = z_scratch + (size_t)(K_ - 1) * chunk;
+    for (size_t first = 0; first < n; first += chunk) {
+        uint32_t count = (uint32_t)(n - first < chunk ? n - first : chunk);
+        hipLaunchKernelGGL(msm_table_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, stream_, points_.as<G1Affine>(),
+                           (uint32_t)n, (uint32_t)first, count, c_, K_, z_scratch, prefix_scratch);
+    }
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(stream_));
 }
 
 void MsmEngine::load_points(const uint64_t *xy_host, const uint8_t *infinity_host, size_t n) {
     ZK_REQUIRE(xy_host != nullptr || n == 0, ZKGPU_ERR_INVALID_ARG, "srs_load: null points");
     ZK_REQUIRE(n < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "srs_load: more than 2^31 - 1 points");
-    points_.reserve(n * sizeof(G1Affine) + 16);
+    n_points_ = 0;
+    const uint32_t c = window_override_ ? window_override_ : choose_window(n);
+    points_.reserve((size_t)(255 / c + 1) * n * sizeof(G1Affine) + 16);
     if (n) ZK_HIP(hipMemcpyAsync(points_.p, xy_host, n * sizeof(G1Affine), hipMemcpyHostToDevice, stream_));
     if (infinity_host && n) {
         bool any = false;
@@ -422,56 +559,58 @@ void MsmEngine::load_points(const uint64_t *xy_host, const uint8_t *infinity_hos
         }
     }
     ZK_HIP(hipStreamSynchronize(stream_));
-    n_points_ = n;
+    build_table(n);
 }
 
 void MsmEngine::load_points_device(const void *xy_dev, size_t n) {
     ZK_REQUIRE(xy_dev != nullptr || n == 0, ZKGPU_ERR_INVALID_ARG, "srs_load: null points");
     ZK_REQUIRE(n < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "srs_load: more than 2^31 - 1 points");
-    points_.reserve(n * sizeof(G1Affine) + 16);
+    n_points_ = 0;
+    const uint32_t c = window_override_ ? window_override_ : choose_window(n);
+    points_.reserve((size_t)(255 / c + 1) * n * sizeof(G1Affine) + 16);
     if (n) ZK_HIP(hipMemcpyAsync(points_.p, xy_dev, n * sizeof(G1Affine), hipMemcpyDeviceToDevice, stream_));
     ZK_HIP(hipStreamSynchronize(stream_));
-    n_points_ = n;
+    build_table(n);
 }
 
-// Window width: about log2(n) - 4 bits keeps the ~2^(c-1) * ceil(255/c) buckets at ~n/2 (32 points per bucket
-// for uniform scalars), so accumulation dominates the bucket reduction and every bucket thread has work.
-uint32_t MsmEngine::choose_window(size_t n) {
-    uint32_t lg = 0;
-    while ((1ull << (lg + 1)) <= n) lg++;
-    int c = (int)lg - 4;
-    if (c < 4) c = 4;
-    if (c > 20) c = 20;
-    return (uint32_t)c;
-}
-
-void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_t &n_windows, uint32_t &window_bits) {
+void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_t &n_groups, uint32_t &log_seg_out) {
     ZK_REQUIRE(base + n <= n_points_, ZKGPU_ERR_INVALID_ARG, "msm: more scalars than loaded points");
     ZK_REQUIRE(n >= 1 && n < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "msm: bad length");
-    const uint32_t c = window_override_ ? window_override_ : choose_window(n);
-    const uint32_t K = 255 / c + 1;
+    const uint32_t c = c_, K = K_;
     const uint32_t log_B = c - 1, B = 1u << log_B;
-    const uint32_t nb = K * B;
-    const uint64_t max_entries = (uint64_t)n * K;
-    ZK_REQUIRE(max_entries < (1ull << 32), ZKGPU_ERR_INVALID_ARG, "msm: too many (point, window) pairs for 32-bit offsets");
-    const uint32_t max_tasks = (uint32_t)(max_entries / BIG_BUCKET + 1);
-    const uint32_t n_scan_blocks = ceil_div(nb, SCAN_ITEMS);
-    const uint32_t log_seg = log_B < 3 ? log_B : 3;
-    const uint32_t segs_per_window = 1u << (log_B - log_seg);
-    const uint32_t n_seg_threads = K * segs_per_window;
+    const uint64_t n_items64 = (uint64_t)n * K;
+    ZK_REQUIRE(n_items64 < (1ull << 32) - 2048, ZKGPU_ERR_INVALID_ARG, "msm: too many (point, window) pairs for 32-bit offsets");
+    const uint32_t n_items = (uint32_t)n_items64;
+    uint32_t class_shift = 0;   // oversize threshold = 256 << shift >= four times the mean bucket size
+    while (((uint64_t)BIG_BUCKET << class_shift) < 4 * (n_items64 >> log_B) && class_shift < 12) class_shift++;
+    const uint32_t big = BIG_BUCKET << class_shift;
+    const uint32_t max_tasks = (uint32_t)(n_items64 / big + 1);
+    const uint32_t n_scan_blocks = ceil_div(B, SCAN_ITEMS);
+    const uint32_t log_seg = log_B < seg_bits_ ? log_B : seg_bits_;
+    const uint32_t n_segments = 1u << (log_B - log_seg);
+    const uint32_t n_bits = log_B - log_seg;
+    const uint32_t groups = n_bits ? n_bits + 3 : 2;
+    // two resident workgroups per CU run these latency-bound sums in a single round: ~512 workgroups in total
+    uint32_t blocks_per_group = 512 / groups;
+    const uint32_t max_useful = ceil_div(n_bits ? n_segments / 2 : 1, 256);
+    if (blocks_per_group > max_useful) blocks_per_group = max_useful;
+    if (blocks_per_group < 1) blocks_per_group = 1;
 
     // sort geometry: bucket ranges of at most 2^15 (128 KiB of LDS counters), slices so that ~1024 workgroups exist
     const uint32_t log_range = log_B < 15 ? log_B : 15;
     const uint32_t n_ranges = 1u << (log_B - log_range);
-    uint32_t S = 1024 / (K * n_ranges);
+    uint32_t S = 1024 / n_ranges;
     if (S < 1) S = 1;
-    while (S > 1 && n / S < 8192) S >>= 1;  // keep slices long enough to amortise the histogram flush
+    while (S > 1 && n_items / S < 8192) S >>= 1;  // keep slices long enough to amortise the histogram flush
     SortGeom geom;
+    geom.n_items = n_items;
     geom.n = (uint32_t)n;
+    geom.stride = (uint32_t)n_points_;
+    geom.base = (uint32_t)base;
     geom.B = B;
     geom.log_range = log_range;
     geom.S = S;
-    geom.slice = (uint32_t)((n + S - 1) / S);
+    geom.slice = (uint32_t)((n_items64 + S - 1) / S);
     const size_t lds_bytes = (size_t)4 << log_range;
     if (!lds_attr_set_) {
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort_kernel<0>),
@@ -481,80 +620,90 @@ void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_
         lds_attr_set_ = true;
     }
 
-    counts_.reserve((size_t)nb * 4);
-    offsets_.reserve((size_t)nb * 4);
-    cursor_.reserve((size_t)nb * S * 4);                 // per-(window, slice, bucket) counts, then cursors
-    order_.reserve((size_t)nb * 4 + (N_CLASSES + 1) * 4);
-    digits_.reserve(max_entries * 4);
+    counts_.reserve((size_t)B * 4);
+    offsets_.reserve((size_t)B * 4);
+    cursor_.reserve((size_t)B * S * 4);                 // per-(slice, bucket) counts, then cursors
+    order_.reserve((size_t)B * 4 + (N_CLASSES + 1) * 4);
+    digits_.reserve(n_items64 * 4);
     block_sums_.reserve((size_t)n_scan_blocks * 4 + 4);
-    sorted_.reserve(max_entries * 4);
-    buckets_.reserve((size_t)nb * sizeof(G1Proj));
+    sorted_.reserve(n_items64 * 4);
+    buckets_.reserve((size_t)B * sizeof(G1Proj));
     tasks_.reserve((size_t)max_tasks * sizeof(MsmTask) + 16);
-    partials_.reserve((size_t)max_tasks * sizeof(G1Proj));
-    seg_.reserve((size_t)n_seg_threads * sizeof(G1Proj));
-    window_sums_.reserve((size_t)K * sizeof(G1Proj));
+    const size_t group_partials = (size_t)groups * blocks_per_group;
+    partials_.reserve((max_tasks > group_partials ? max_tasks : group_partials) * sizeof(G1Proj));
+    seg_.reserve((size_t)2 * n_segments * sizeof(G1Proj));
+    group_sums_.reserve((size_t)groups * sizeof(G1Proj));
     uint32_t *task_count = reinterpret_cast<uint32_t *>(tasks_.as<char>() + (size_t)max_tasks * sizeof(MsmTask));
     uint32_t *order = order_.as<uint32_t>();
-    uint32_t *class_cursor = order + nb;
+    uint32_t *class_cursor = order + B;
+    G1Proj *t_seg = seg_.as<G1Proj>(), *w_seg = t_seg + n_segments;
 
-    const G1Affine *pts = points_.as<G1Affine>() + base;
+    const G1Affine *table = points_.as<G1Affine>();
     ZK_HIP(hipMemsetAsync(task_count, 0, 4, stream_));
     ZK_HIP(hipMemsetAsync(class_cursor, 0, (N_CLASSES + 1) * 4, stream_));
     hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, scalars_dev, (uint32_t)n, c, K,
                        digits_.as<uint32_t>());
-    const dim3 sort_grid(S, n_ranges, K);
+    const dim3 sort_grid(S, n_ranges);
     hipLaunchKernelGGL(msm_sort_kernel<0>, sort_grid, dim3(1024), lds_bytes, stream_, digits_.as<uint32_t>(), geom,
                        cursor_.as<uint32_t>(), sorted_.as<uint32_t>());
-    hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, cursor_.as<uint32_t>(), nb, B, S,
+    hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, cursor_.as<uint32_t>(), B, S,
                        counts_.as<uint32_t>());
     hipLaunchKernelGGL(scan_block_kernel, dim3(n_scan_blocks), dim3(256), 0, stream_, counts_.as<uint32_t>(),
-                       offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb);
+                       offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), B);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream_, block_sums_.as<uint32_t>(), n_scan_blocks);
-    hipLaunchKernelGGL(scan_finish_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, counts_.as<uint32_t>(),
-                       offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb, tasks_.as<MsmTask>(), task_count, max_tasks);
-    hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, cursor_.as<uint32_t>(),
-                       offsets_.as<uint32_t>(), nb, B, S);
+    hipLaunchKernelGGL(scan_finish_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, counts_.as<uint32_t>(),
+                       offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), B, big, tasks_.as<MsmTask>(), task_count, max_tasks);
+    hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, cursor_.as<uint32_t>(),
+                       offsets_.as<uint32_t>(), B, S);
     hipLaunchKernelGGL(msm_sort_kernel<1>, sort_grid, dim3(1024), lds_bytes, stream_, digits_.as<uint32_t>(), geom,
                        cursor_.as<uint32_t>(), sorted_.as<uint32_t>());
     // schedule: class histogram, scan, placement
-    hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(nb, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), nb,
-                       class_cursor, order);
+    hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
+                       class_shift, class_cursor, order);
     hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(1), dim3(64), 0, stream_, class_cursor);
-    hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(nb, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), nb,
-                       class_cursor, order);
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, pts, sorted_.as<uint32_t>(),
+    hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
+                       class_shift, class_cursor, order);
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, table, sorted_.as<uint32_t>(),
                        offsets_.as<uint32_t>(), counts_.as<uint32_t>(), order, class_cursor + N_CLASSES, buckets_.as<G1Proj>());
     const uint32_t big_grid = max_tasks < 2048 ? max_tasks : 2048;
-    hipLaunchKernelGGL(msm_big_partial_kernel, dim3(big_grid), dim3(256), 0, stream_, pts, sorted_.as<uint32_t>(),
+    hipLaunchKernelGGL(msm_big_partial_kernel, dim3(big_grid), dim3(256), 0, stream_, table, sorted_.as<uint32_t>(),
                        tasks_.as<MsmTask>(), task_count, max_tasks, partials_.as<G1Proj>());
     hipLaunchKernelGGL(msm_big_combine_kernel, dim3(big_grid), dim3(256), 0, stream_, tasks_.as<MsmTask>(), task_count,
                        max_tasks, partials_.as<G1Proj>(), buckets_.as<G1Proj>());
-    hipLaunchKernelGGL(msm_segment_kernel, dim3(ceil_div(n_seg_threads, 256)), dim3(256), 0, stream_, buckets_.as<G1Proj>(),
-                       log_B, log_seg, n_seg_threads, seg_.as<G1Proj>());
-    hipLaunchKernelGGL(msm_window_kernel, dim3(K), dim3(256), 0, stream_, seg_.as<G1Proj>(), segs_per_window,
-                       window_sums_.as<G1Proj>());
+    // reduction (partials_ is free again: the oversized-bucket kernels above have consumed it in stream order)
+    hipLaunchKernelGGL(msm_segment_kernel, dim3(ceil_div(n_segments, 256)), dim3(256), 0, stream_, buckets_.as<G1Proj>(), log_seg,
+                       n_segments, t_seg, w_seg);
+    hipLaunchKernelGGL(msm_group_partial_kernel, dim3(blocks_per_group, groups), dim3(256), 0, stream_, t_seg, w_seg, n_segments,
+                       n_bits, partials_.as<G1Proj>());
+    hipLaunchKernelGGL(msm_group_final_kernel, dim3(groups), dim3(256), 0, stream_, partials_.as<G1Proj>(), blocks_per_group,
+                       group_sums_.as<G1Proj>());
     ZK_HIP(hipGetLastError());
-    n_windows = K;
-    window_bits = c;
+    n_groups = groups;
+    log_seg_out = log_seg;
 }
 
-G1Proj MsmEngine::finish(uint32_t K, uint32_t c) {
-    std::vector<G1Proj> ws(K);
-    ZK_HIP(hipMemcpyAsync(ws.data(), window_sums_.p, (size_t)K * sizeof(G1Proj), hipMemcpyDeviceToHost, stream_));
+G1Proj MsmEngine::finish(uint32_t groups, uint32_t log_seg) {
+    std::vector<G1Proj> gs(groups);
+    ZK_HIP(hipMemcpyAsync(gs.data(), group_sums_.p, (size_t)groups * sizeof(G1Proj), hipMemcpyDeviceToHost, stream_));
     ZK_HIP(hipStreamSynchronize(stream_));
-    // Horner over the windows, highest first (multiscalar_mul.rs:207-219 does the same with its own window size)
+    // sum_b (b+1) bucket_b = sum_s W_s + L * sum_k 2^k Q_k + sum_s T_s (group layout: msm_group_partial_kernel)
+    if (groups == 2) return g1_add(gs[0], gs[1]);
+    const uint32_t n_bits = groups - 3;
     G1Proj total = G1Proj::identity();
-    for (int w = (int)K - 1; w >= 0; w--) {
-        for (uint32_t k = 0; k < c; k++) total = g1_double(total);
-        total = g1_add(total, ws[w]);
+    for (int k = (int)n_bits - 1; k >= 0; k--) {
+        total = g1_double(total);
+        total = g1_add(total, gs[k]);
     }
+    for (uint32_t k = 0; k < log_seg; k++) total = g1_double(total);
+    total = g1_add(total, g1_add(gs[n_bits - 1], gs[n_bits]));
+    total = g1_add(total, g1_add(gs[n_bits + 1], gs[n_bits + 2]));
     return total;
 }
 
 G1Proj MsmEngine::msm(const Fr *scalars_dev, size_t n, size_t base) {
-    uint32_t K, c;
-    msm_device(scalars_dev, n, base, K, c);
-    return finish(K, c);
+    uint32_t groups, log_seg;
+    msm_device(scalars_dev, n, base, groups, log_seg);
+    return finish(groups, log_seg);
 }
 
 }  // namespace zk

@@ -14,7 +14,8 @@ class MsmEngine {
     ~MsmEngine();
 
     // Uploads n affine points (x | y, 12 x u64 Montgomery limbs each = the first 96 bytes of the reference's
-    // raw point encoding, g1/coset.rs:8-24).  `infinity` may be null.  Replaces any previous table.
+    // raw point encoding, g1/coset.rs:8-24) and extends them on the device to the table of window multiples
+    // 2^(c w) * P_i.  `infinity` may be null.  Replaces any previous table.
     void load_points(const uint64_t *xy_host, const uint8_t *infinity_host, size_t n);
     // Same, from a device buffer of n x 96 bytes (copied; infinity = all-zero x and y).
     void load_points_device(const void *xy_dev, size_t n);
@@ -24,20 +25,27 @@ class MsmEngine {
     // (device memory).  Synchronous: returns the projective sum after the device work has finished.
     G1Proj msm(const Fr *scalars_dev, size_t n, size_t base = 0);
 
-    // Device phase only: leaves the per-window sums in an internal buffer and returns their count and window
-    // width; finish() then combines them on the host.  Used to time the kernels without the host tail.
-    void msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_t &n_windows, uint32_t &window_bits);
-    G1Proj finish(uint32_t n_windows, uint32_t window_bits);
+    // Device phase only: leaves the group sums of the bucket reduction in an internal buffer and returns their
+    // count and the segment width; finish() then combines them on the host.  Used to time the kernels alone.
+    void msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_t &n_groups, uint32_t &log_seg);
+    G1Proj finish(uint32_t n_groups, uint32_t log_seg);
 
     static uint32_t choose_window(size_t n);
     size_t device_bytes() const;
+    // Test hooks: window width used by the next load_points*, segment width of the bucket reduction.
     void set_window_override(uint32_t c) { window_override_ = c; }
+    void set_segment_bits(uint32_t b) { seg_bits_ = b; }
+    uint32_t window_bits() const { return c_; }
+    uint32_t n_windows() const { return K_; }
 
    private:
     hipStream_t stream_;
-    DevBuf points_;
+    void build_table(size_t n);
+
+    DevBuf points_;  // table[w * n_points + i] = 2^(c w) * P_i, affine, K levels
     size_t n_points_ = 0;
-    DevBuf counts_, offsets_, cursor_, sorted_, buckets_, block_sums_, tasks_, partials_, misc_, seg_, window_sums_;
+    uint32_t c_ = 0, K_ = 0, seg_bits_ = 3;
+    DevBuf counts_, offsets_, cursor_, sorted_, buckets_, block_sums_, tasks_, partials_, misc_, seg_, group_sums_;
     DevBuf order_, digits_;
     uint32_t window_override_ = 0;
     bool lds_attr_set_ = false;

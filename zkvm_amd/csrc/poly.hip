@@ -171,13 +171,10 @@ __global__ void __launch_bounds__(256) perm_numden_kernel(PermArgs a, Fr *num, F
 }
 
 // z[i] = (prod_{j<i} num_j) * (prod_{j>=i} den_j) / (prod_j den_j)
-__global__ void __launch_bounds__(256) perm_finish_kernel(const Fr *pnum_incl, const Fr *sden_incl, uint32_t n, Fr *z) {
-    __shared__ uint32_t inv_sh[8];
-    if (threadIdx.x == 0) lds_st(inv_sh, 0, Fr::inv(ld(sden_incl)));
-    __syncthreads();
+__global__ void __launch_bounds__(256) perm_finish_kernel(const Fr *pnum_incl, const Fr *sden_incl, Fr inv_total, uint32_t n,
+                                                          Fr *z) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Fr inv_total = lds_ld(inv_sh, 0);
     Fr v = Fr::mul(ld(sden_incl + i), inv_total);
     if (i) v = Fr::mul(v, ld(pnum_incl + i - 1));
     st(z + i, v);
@@ -201,7 +198,12 @@ void PolyEngine::permutation_z(const Fr *const wires[4], const Fr *const sigma_e
     hipLaunchKernelGGL(perm_numden_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, a, num, den);
     inclusive_scan<OpMul, false>(stream_, num, num, n, s2_);
     inclusive_scan<OpMul, true>(stream_, den, den, n, s2_);
-    hipLaunchKernelGGL(perm_finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, num, den, n, z_out);
+    // the one inversion of the whole accumulator: a single field element, so it is cheaper on the host than as a
+    // ~100k-instruction dependent chain on one GPU lane
+    Fr total;
+    ZK_HIP(hipMemcpyAsync(&total, den, sizeof(Fr), hipMemcpyDeviceToHost, stream_));
+    ZK_HIP(hipStreamSynchronize(stream_));
+    hipLaunchKernelGGL(perm_finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, num, den, Fr::inv(total), n, z_out);
     ZK_HIP(hipGetLastError());
 }
 
@@ -428,24 +430,36 @@ void PolyEngine::patch(Fr *p, const uint64_t *idx, const Fr *vals, const bool *s
 
 // ---- degree -------------------------------------------------------------------------------------------------
 // *out = 1 + index of the highest non-zero coefficient (0 for the zero polynomial)
-__global__ void __launch_bounds__(256) degree_kernel(const Fr *coeffs, uint64_t len, unsigned long long *out) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(1024) degree_kernel(const Fr *coeffs, uint64_t len, unsigned long long *out) {
+    __shared__ unsigned long long wave_max[16];
+    // blocks walk the vector from the top, so the block holding the leading coefficient is among the first to run
+    const uint64_t block_from_top = gridDim.x - 1 - blockIdx.x;
+    const uint64_t base = block_from_top * 4096 + threadIdx.x;
     unsigned long long mine = 0;
-    if (i < len && !ld(coeffs + i).is_zero()) mine = i + 1;
-    // wave-level maximum first, then one atomic per wave
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t i = base + (uint64_t)k * 1024;
+        if (i < len && !ld(coeffs + i).is_zero()) mine = i + 1;   // later k = higher index
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         unsigned long long o = __shfl_xor(mine, d);
         mine = o > mine ? o : mine;
     }
-    if ((threadIdx.x & 63) == 0 && mine) atomicMax(out, mine);
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < 16; w++) mine = wave_max[w] > mine ? wave_max[w] : mine;
+        // a stale read only costs an extra atomic
+        if (mine > *reinterpret_cast<volatile unsigned long long *>(out)) atomicMax(out, mine);
+    }
 }
 uint64_t PolyEngine::length_without_leading_zeros(const Fr *coeffs, uint64_t len) {
     if (len == 0) return 0;
     jobs_.reserve(64);
     unsigned long long *d = jobs_.as<unsigned long long>();
     ZK_HIP(hipMemsetAsync(d, 0, 8, stream_));
-    hipLaunchKernelGGL(degree_kernel, dim3(ceil_div(len, 256)), dim3(256), 0, stream_, coeffs, len, d);
+    hipLaunchKernelGGL(degree_kernel, dim3(ceil_div(len, 4096)), dim3(1024), 0, stream_, coeffs, len, d);
     ZK_HIP(hipGetLastError());
     unsigned long long h = 0;
     ZK_HIP(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream_));

@@ -85,6 +85,10 @@ int zkgpu_ntt(zkgpu_ctx *ctx, uint64_t *data, size_t len_in, uint32_t log_n, int
  * out_dev must hold 2^log_n elements. */
 int zkgpu_ntt_dev(zkgpu_ctx *ctx, const void *in_dev, size_t len_in, void *out_dev, uint32_t log_n, int mode);
 
+/* Tuning knobs of the transform, for experiments and tests: log2 of the LDS tile in elements (6..12, 0 = default)
+ * and log2 of the elements each thread carries per stage (1..3, 0 = default).  Results do not depend on them. */
+int zkgpu_ntt_set_params(zkgpu_ctx *ctx, uint32_t tile_log, uint32_t elems_per_thread_log);
+
 /* ---- CommitKey ------------------------------------------------------------------------------------------ */
 /* Uploads CommitKey.powers_of_g (plonk/src/commitment_scheme/kzg10/key.rs:32-35) once; it stays resident, as
  * the reference's Prover holds its commit_key by value (plonk/src/compiler/prover.rs:22-30).
@@ -119,6 +123,13 @@ int zkgpu_msm_kernels_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n);
  * coefficients as held by the reference's Polynomial (leading zeros allowed; the degree is computed as
  * Polynomial::degree does).  ZKGPU_ERR_DEGREE_ZERO / ZKGPU_ERR_DEGREE_LARGE mirror the reference's errors. */
 int zkgpu_commit(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, uint64_t out_xy[12], uint8_t *out_infinity);
+
+/* Host-only self-check of the bucket arithmetic used inside the MSM kernels (28-bit unsaturated limbs, extended
+ * Jacobian mixed additions): adds the n affine points in order, point i negated when negate[i] != 0, and returns the
+ * sum as a projective point.  *violations receives the number of products whose operands broke the limb or
+ * magnitude bounds that the device code relies on (0 on a correct build). */
+int zkgpu_g1_bucket_selfcheck(const uint64_t *xy, const uint8_t *infinity, const uint8_t *negate, size_t n,
+                              uint64_t out_xyz[18], uint64_t *violations);
 
 /* G1Affine::to_bytes (coset-bls12_381/src/g1/coset.rs:54-71): the 48-byte compressed encoding that the
  * transcript absorbs.  Host-only. */

@@ -125,3 +125,17 @@ def test_domain_size_error(ctx):
         zkvm_amd.EvaluationDomain(1 << 32)
     d = zkvm_amd.EvaluationDomain(5, ctx)
     assert d.size == 8 and d.log_size_of_group == 3
+
+
+@pytest.mark.parametrize("tile_log,ept_log", [(6, 1), (7, 3), (9, 2), (10, 1), (12, 1), (12, 2)])
+def test_ntt_tile_sizes(ctx, orc, tile_log, ept_log):
+    """Every tile size cuts the network into different passes; all of them give the oracle's result."""
+    try:
+        ctx.ntt_set_params(tile_log, ept_log)
+        for log_n in (5, 13, 16):
+            n = 1 << log_n
+            x = M.random_fr_mont(n - 3, seed=tile_log * 100 + log_n)
+            for mode, name in ((0, "fft"), (1, "ifft"), (2, "coset_fft"), (3, "coset_ifft")):
+                assert np.array_equal(ctx.ntt(x, log_n, mode), orc.fft(name, x, n)), (name, log_n)
+    finally:
+        ctx.ntt_set_params(0, 0)

@@ -106,6 +106,10 @@ class Context:
         self._check(self._lib.zkgpu_ntt(self._h, buf.ctypes.data, len_in if len_in <= n else n, log_n, mode))
         return buf
 
+    def ntt_set_params(self, tile_log=0, elems_per_thread_log=0):
+        """Tuning knobs of the transform (0 = default)."""
+        self._check(self._lib.zkgpu_ntt_set_params(self._h, int(tile_log), int(elems_per_thread_log)))
+
     # ---- SRS / MSM --------------------------------------------------------------------------------------
     def srs_load(self, xy, infinity=None):
         if _is_torch(xy):
@@ -160,6 +164,21 @@ def g1_sum_to_affine(xyz):
     if rc != 0:
         raise ZkGpuError(rc, "g1_sum_to_affine")
     return out, int(inf.value)
+
+
+def g1_bucket_selfcheck(xy, negate=None, infinity=None):
+    """Host-side run of the MSM kernels' bucket arithmetic -> (projective sum (18,), bound violations)."""
+    pts = _np_u64(xy, 12)
+    n = pts.shape[0]
+    neg = np.ascontiguousarray(negate if negate is not None else np.zeros(n), dtype=np.uint8)
+    inf = np.ascontiguousarray(infinity if infinity is not None else np.zeros(n), dtype=np.uint8)
+    out = np.zeros(18, dtype=np.uint64)
+    viol = C.c_uint64(0)
+    rc = _lib.lib().zkgpu_g1_bucket_selfcheck(pts.ctypes.data if n else None, inf.ctypes.data if n else None,
+                                              neg.ctypes.data if n else None, n, out.ctypes.data, C.addressof(viol))
+    if rc != 0:
+        raise ZkGpuError(rc, "g1_bucket_selfcheck")
+    return out, int(viol.value)
 
 
 def g1_compress(xy, infinity=0):

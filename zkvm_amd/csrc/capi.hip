@@ -2,6 +2,7 @@
 #include "../../include/zkgpu.h"
 #include "common.hpp"
 #include "msm.hpp"
+#include "fq28.cuh"
 #include "ntt.hpp"
 #include "poly.hpp"
 #include "prover.hpp"
@@ -200,6 +201,15 @@ int zkgpu_msm_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, uint64_t ou
     });
 }
 
+int zkgpu_ntt_set_params(zkgpu_ctx *ctx, uint32_t tile_log, uint32_t elems_per_thread_log) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(tile_log == 0 || (tile_log >= 6 && tile_log <= 12), ZKGPU_ERR_INVALID_ARG,
+                   "ntt_set_params: tile_log must be 0 or within 6..12");
+        ZK_REQUIRE(elems_per_thread_log <= 3, ZKGPU_ERR_INVALID_ARG, "ntt_set_params: elems_per_thread_log must be within 0..3");
+        ctx->ntt->set_tile(tile_log ? tile_log : NTT_DEFAULT_TILE_LOG, elems_per_thread_log ? elems_per_thread_log : NTT_DEFAULT_EPT_LOG);
+    });
+}
+
 int zkgpu_msm_set_params(zkgpu_ctx *ctx, uint32_t window_bits, uint32_t segment_bits) {
     return guarded(ctx, [&] {
         ZK_REQUIRE(window_bits == 0 || (window_bits >= 4 && window_bits <= 22), ZKGPU_ERR_INVALID_ARG,
@@ -276,6 +286,26 @@ int zkgpu_commit(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, uint64_t ou
         ZK_HIP(hipMemcpyAsync(ctx->stage_b.p, coeffs, m * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
         msm_checked(ctx, ctx->stage_b.as<Fr>(), m, out_xy, out_infinity);
     });
+}
+
+int zkgpu_g1_bucket_selfcheck(const uint64_t *xy, const uint8_t *infinity, const uint8_t *negate, size_t n,
+                              uint64_t out_xyz[18], uint64_t *violations) {
+    if ((!xy && n) || !out_xyz) return ZKGPU_ERR_INVALID_ARG;
+    const long before = fq28_violations();
+    G1Xyzz acc = G1Xyzz::identity();
+    for (size_t i = 0; i < n; i++) {
+        G1Affine p;
+        memcpy(&p, xy + 12 * i, sizeof p);
+        if (infinity && infinity[i]) {
+            p.x = Fq::zero();
+            p.y = Fq::zero();
+        }
+        acc = xyzz_add_mixed(acc, affine_to_28(p), negate && negate[i]);
+    }
+    G1Proj r = xyzz_to_proj(acc);
+    memcpy(out_xyz, &r, sizeof r);
+    if (violations) *violations = (uint64_t)(fq28_violations() - before);
+    return ZKGPU_OK;
 }
 
 int zkgpu_g1_compress(const uint64_t xy[12], uint8_t infinity, uint8_t out[48]) {

@@ -22,6 +22,7 @@
 // (multiscalar_mul.rs:150-195) change only the order of group additions; the sum, and so the affine
 // commitment compared by the tests, is the same group element.
 #include "msm.hpp"
+#include "fq28.cuh"
 
 namespace zk {
 
@@ -61,6 +62,33 @@ __device__ __forceinline__ G1Affine gload_affine(const G1Affine *p) {
     r.x = gload_fq(q);
     r.y = gload_fq(q + 3);
     return r;
+}
+__device__ __forceinline__ G1Affine28 gload_affine28(const G1Affine28 *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    G1Affine28 r;
+    uint32_t w[28];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        uint4 t = q[k];
+        w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        r.x.v[k] = w[k];
+        r.y.v[k] = w[14 + k];
+    }
+    return r;
+}
+__device__ __forceinline__ void gstore_affine28(G1Affine28 *p, const G1Affine28 &a) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    uint32_t w[28];
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        w[k] = a.x.v[k];
+        w[14 + k] = a.y.v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) q[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
 }
 __device__ __forceinline__ G1Proj gload_proj(const G1Proj *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
@@ -279,7 +307,7 @@ __global__ void msm_schedule_scan_kernel(uint32_t *class_cursor) {
 }
 
 // ---- bucket accumulation ----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) msm_accumulate_kernel(const G1Affine *points, const uint32_t *sorted,
+__global__ void __launch_bounds__(256) msm_accumulate_kernel(const G1Affine28 *points, const uint32_t *sorted,
                                                              const uint32_t *offsets, const uint32_t *counts,
                                                              const uint32_t *order, const uint32_t *n_scheduled,
                                                              G1Proj *buckets) {
@@ -287,13 +315,13 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const G1Affine *poi
     if (gid >= *n_scheduled) return;
     const uint32_t b = order[gid];
     const uint32_t cnt = counts[b], start = offsets[b];
-    G1Proj acc = G1Proj::identity();
+    G1Xyzz acc = G1Xyzz::identity();
     for (uint32_t k = 0; k < cnt; k++) {
         uint32_t v = sorted[start + k];
-        G1Affine p = gload_affine(points + (v & 0x7fffffffu));
-        acc = g1_add_mixed(acc, p, (v >> 31) != 0);
+        G1Affine28 p = gload_affine28(points + (v & 0x7fffffffu));
+        acc = xyzz_add_mixed(acc, p, (v >> 31) != 0);
     }
-    gstore_proj(buckets + b, acc);
+    gstore_proj(buckets + b, xyzz_to_proj(acc));
 }
 
 __device__ __forceinline__ void lds_store_proj(uint32_t *sh, uint32_t slot, const G1Proj &p) {
@@ -329,7 +357,7 @@ __device__ __forceinline__ G1Proj block_tree_sum(uint32_t *sh, G1Proj acc, uint3
     return acc;
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_big_partial_kernel(const G1Affine *points, const uint32_t *sorted,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_big_partial_kernel(const G1Affine28 *points, const uint32_t *sorted,
                                                               const MsmTask *tasks, const uint32_t *task_count,
                                                               uint32_t max_tasks, G1Proj *partials) {
     __shared__ uint32_t sh[128 * 36];
@@ -337,13 +365,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (n_tasks > max_tasks) n_tasks = max_tasks;
     for (uint32_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
         MsmTask task = tasks[t];
-        G1Proj acc = G1Proj::identity();
+        G1Xyzz part = G1Xyzz::identity();
         for (uint32_t k = threadIdx.x; k < task.len; k += 256) {
             uint32_t v = sorted[task.start + k];
-            G1Affine p = gload_affine(points + (v & 0x7fffffffu));
-            acc = g1_add_mixed(acc, p, (v >> 31) != 0);
+            G1Affine28 p = gload_affine28(points + (v & 0x7fffffffu));
+            part = xyzz_add_mixed(part, p, (v >> 31) != 0);
         }
-        acc = block_tree_sum(sh, acc);
+        G1Proj acc = block_tree_sum(sh, xyzz_to_proj(part));
         if (threadIdx.x == 0) gstore_proj(partials + t, acc);
     }
 }
@@ -440,14 +468,19 @@ __device__ __forceinline__ void gstore_affine(G1Affine *p, const Fq &x, const Fq
 // Thread t extends point first + t: level w holds 2^(c w) * P in affine form.  The projective multiples are
 // written unnormalised first; their Z coordinates and running products go to scratch so that one inversion per
 // point converts all levels (Montgomery's trick along the levels).
-__global__ void __launch_bounds__(256) msm_table_kernel(G1Affine *table, uint32_t stride, uint32_t first, uint32_t count,
-                                                        uint32_t c, uint32_t K, Fq *z_scratch, Fq *prefix_scratch) {
+__global__ void __launch_bounds__(256) msm_table_kernel(G1Affine *table, G1Affine28 *table28, uint32_t stride, uint32_t first,
+                                                        uint32_t count, uint32_t c, uint32_t K, Fq *z_scratch,
+                                                        Fq *prefix_scratch) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const uint32_t i = first + t;
     const G1Affine p = gload_affine(table + i);
+    gstore_affine28(table28 + i, affine_to_28(p));
     if (p.is_identity()) {
-        for (uint32_t w = 1; w < K; w++) gstore_affine(table + (size_t)w * stride + i, Fq::zero(), Fq::zero());
+        G1Affine28 inf;
+        inf.x = Fq28::zero();
+        inf.y = Fq28::zero();
+        for (uint32_t w = 1; w < K; w++) gstore_affine28(table28 + (size_t)w * stride + i, inf);
         return;
     }
     G1Proj q;
@@ -470,14 +503,19 @@ __global__ void __launch_bounds__(256) msm_table_kernel(G1Affine *table, uint32_
         Fq z = gload_fq(reinterpret_cast<const uint4 *>(z_scratch + (size_t)(w - 1) * count + t));
         G1Affine *slot = table + (size_t)w * stride + i;
         if (z.is_zero()) {
-            gstore_affine(slot, Fq::zero(), Fq::zero());
+            G1Affine28 inf;
+            inf.x = Fq28::zero();
+            inf.y = Fq28::zero();
+            gstore_affine28(table28 + (size_t)w * stride + i, inf);
             continue;
         }
         Fq zinv = inv;
         if (w > 1) zinv = Fq::mul(inv, gload_fq(reinterpret_cast<const uint4 *>(prefix_scratch + (size_t)(w - 2) * count + t)));
         inv = Fq::mul(inv, z);
         G1Affine u = gload_affine(slot);
-        gstore_affine(slot, Fq::mul(u.x, zinv), Fq::mul(u.y, zinv));
+        u.x = Fq::mul(u.x, zinv);
+        u.y = Fq::mul(u.y, zinv);
+        gstore_affine28(table28 + (size_t)w * stride + i, affine_to_28(u));
     }
 }
 
@@ -493,13 +531,13 @@ __global__ void msm_mark_infinity_kernel(G1Affine *points, const uint8_t *inf, u
 // ---------------------------------------------------------------------------------------------------------
 MsmEngine::~MsmEngine() {
     DevBuf *all[] = {&points_, &counts_, &offsets_, &cursor_, &sorted_, &buckets_, &block_sums_, &tasks_, &partials_,
-                     &misc_,   &seg_,    &group_sums_, &order_, &digits_};
+                     &misc_,   &seg_,    &group_sums_, &order_, &digits_, &table28_};
     for (DevBuf *b : all) b->release();
 }
 
 size_t MsmEngine::device_bytes() const {
     return points_.cap + counts_.cap + offsets_.cap + cursor_.cap + sorted_.cap + buckets_.cap + block_sums_.cap +
-           tasks_.cap + partials_.cap + misc_.cap + seg_.cap + group_sums_.cap + order_.cap + digits_.cap;
+           tasks_.cap + partials_.cap + misc_.cap + seg_.cap + group_sums_.cap + order_.cap + digits_.cap + table28_.cap;
 }
 
 // Window width for a table of n points: minimises n * K * 11 products of accumulation plus ~30 products per
@@ -527,14 +565,15 @@ void MsmEngine::build_table(size_t n) {
     K_ = 255 / c_ + 1;
     ZK_REQUIRE((uint64_t)n * K_ < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "srs_load: table of window multiples exceeds 2^31 entries");
     n_points_ = n;
-    if (n == 0 || K_ == 1) return;
+    if (n == 0) return;
+    table28_.reserve((size_t)K_ * n * sizeof(G1Affine28));
     const uint32_t chunk = n < (1u << 18) ? (uint32_t)n : (1u << 18);
     misc_.reserve((size_t)2 * (K_ - 1) * chunk * sizeof(Fq));
     Fq *z_scratch = misc_.as<Fq>(), *prefix_scratch = z_scratch + (size_t)(K_ - 1) * chunk;
     for (size_t first = 0; first < n; first += chunk) {
         uint32_t count = (uint32_t)(n - first < chunk ? n - first : chunk);
         hipLaunchKernelGGL(msm_table_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, stream_, points_.as<G1Affine>(),
-                           (uint32_t)n, (uint32_t)first, count, c_, K_, z_scratch, prefix_scratch);
+                           table28_.as<G1Affine28>(), (uint32_t)n, (uint32_t)first, count, c_, K_, z_scratch, prefix_scratch);
     }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(stream_));
@@ -638,7 +677,7 @@ void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_
     uint32_t *class_cursor = order + B;
     G1Proj *t_seg = seg_.as<G1Proj>(), *w_seg = t_seg + n_segments;
 
-    const G1Affine *table = points_.as<G1Affine>();
+    const G1Affine28 *table = table28_.as<G1Affine28>();
     ZK_HIP(hipMemsetAsync(task_count, 0, 4, stream_));
     ZK_HIP(hipMemsetAsync(class_cursor, 0, (N_CLASSES + 1) * 4, stream_));
     hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, scalars_dev, (uint32_t)n, c, K,

@@ -42,7 +42,8 @@ class MsmEngine {
     hipStream_t stream_;
     void build_table(size_t n);
 
-    DevBuf points_;  // table[w * n_points + i] = 2^(c w) * P_i, affine, K levels
+    DevBuf points_;   // reference-form affine multiples, K levels (kept from the build)
+    DevBuf table28_;  // table[w * n_points + i] = 2^(c w) * P_i, affine, unsaturated limbs (112 bytes), K levels
     size_t n_points_ = 0;
     uint32_t c_ = 0, K_ = 0, seg_bits_ = 3;
     DevBuf counts_, offsets_, cursor_, sorted_, buckets_, block_sums_, tasks_, partials_, misc_, seg_, group_sums_;

@@ -311,10 +311,10 @@ void NttEngine::ensure_coset_powers(uint32_t log_n) {
     gpow_log_ = need;
 }
 
-// Split the k index bits into passes of at most 10 row bits; tiles hold 2^12 elements (128 KiB of LDS).
+// Split the k index bits into passes of at most 10 row bits; tiles hold 2^tile_log_ elements (32 bytes each in LDS).
 std::vector<NttEngine::Pass> NttEngine::plan(uint32_t k) {
     std::vector<Pass> passes;
-    const uint32_t TILE_LOG = 12, MAX_R = 10;
+    const uint32_t TILE_LOG = tile_log_, MAX_R = TILE_LOG < 10 ? TILE_LOG : 10;
     if (k <= TILE_LOG) {
         passes.push_back(Pass{0, k, 0});
         return passes;
@@ -376,7 +376,7 @@ void NttEngine::transform(NttMode mode, const Fr *in, size_t len_in, Fr *out, ui
         a.unit_last = (mode == NTT_COSET_IFFT) ? 0 : 1;
         const uint32_t tile_log = a.log_r + a.log_t;
         const uint64_t E = 1ull << tile_log;
-        uint32_t threads = (uint32_t)(E / 2);
+        uint32_t threads = (uint32_t)(E >> ept_log_);
         if (threads > 1024) threads = 1024;
         if (threads < 64) threads = 64;
         const uint32_t grid = (uint32_t)(n >> tile_log);

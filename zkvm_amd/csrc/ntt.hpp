@@ -19,6 +19,10 @@ struct Domain {
 
 enum NttMode { NTT_FFT = 0, NTT_IFFT = 1, NTT_COSET_FFT = 2, NTT_COSET_IFFT = 3 };
 
+// 2^9-element tiles (16 KiB of LDS, 256 threads): ten workgroups per CU overlap one tile's loads and stores with
+// the butterflies of the others; measured best on MI355X (2^12 tiles leave one workgroup per CU and run 25% slower).
+static const uint32_t NTT_DEFAULT_TILE_LOG = 9, NTT_DEFAULT_EPT_LOG = 1;
+
 class NttEngine {
    public:
     explicit NttEngine(hipStream_t s) : stream_(s) {}
@@ -31,6 +35,11 @@ class NttEngine {
     // Largest transform the twiddle tables currently cover (grown on demand).
     uint32_t table_log() const { return table_log_; }
     size_t device_bytes() const;
+    // Tuning: log2 of the LDS tile (elements) and log2 of the elements per thread.
+    void set_tile(uint32_t tile_log, uint32_t ept_log) {
+        tile_log_ = tile_log;
+        ept_log_ = ept_log;
+    }
 
    private:
     struct Pass {
@@ -39,7 +48,7 @@ class NttEngine {
     void ensure_tables(uint32_t log_n);
     const Fr *coset_inv_table(uint32_t log_n);
     void ensure_coset_powers(uint32_t log_n);
-    static std::vector<Pass> plan(uint32_t log_n);
+    std::vector<Pass> plan(uint32_t log_n);
 
     hipStream_t stream_;
     uint32_t table_log_ = 0;
@@ -50,6 +59,7 @@ class NttEngine {
     DevBuf work_;                       // ping buffer for multi-pass transforms
     DevBuf stage_consts_;
     bool lds_attr_set_ = false;
+    uint32_t tile_log_ = NTT_DEFAULT_TILE_LOG, ept_log_ = NTT_DEFAULT_EPT_LOG;
 };
 
 }  // namespace zk

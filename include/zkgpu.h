@@ -130,6 +130,10 @@ int zkgpu_commit(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, uint64_t ou
  * magnitude bounds that the device code relies on (0 on a correct build). */
 int zkgpu_g1_bucket_selfcheck(const uint64_t *xy, const uint8_t *infinity, const uint8_t *negate, size_t n,
                               uint64_t out_xyz[18], uint64_t *violations);
+/* Same for the accumulator + accumulator additions of the bucket reduction: every point becomes an accumulator
+ * and the accumulators are summed pairwise, level by level, as the device's workgroup trees do. */
+int zkgpu_g1_bucket_selfcheck_tree(const uint64_t *xy, const uint8_t *infinity, const uint8_t *negate, size_t n,
+                                   uint64_t out_xyz[18], uint64_t *violations);
 
 /* G1Affine::to_bytes (coset-bls12_381/src/g1/coset.rs:54-71): the 48-byte compressed encoding that the
  * transcript absorbs.  Host-only. */

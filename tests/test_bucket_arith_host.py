@@ -21,13 +21,14 @@ def _want(orc, pts, neg, inf):
 
 def _check(orc, pts, neg=None, inf=None):
     from zkvm_amd import api
-    out, viol = api.g1_bucket_selfcheck(pts, neg, inf)
-    assert viol == 0
-    got = api.g1_sum_to_affine(out.reshape(1, 18))
     want = _want(orc, pts, neg, inf)
-    assert got[1] == int(want[1])
-    if not got[1]:
-        assert np.array_equal(got[0], want[0])
+    for tree in (False, True):       # point-by-point chain, then pairwise accumulator tree
+        out, viol = api.g1_bucket_selfcheck(pts, neg, inf, tree=tree)
+        assert viol == 0
+        got = api.g1_sum_to_affine(out.reshape(1, 18))
+        assert got[1] == int(want[1])
+        if not got[1]:
+            assert np.array_equal(got[0], want[0])
 
 
 def test_random_chains(orc):
@@ -54,6 +55,9 @@ def test_exceptional_cases(orc):
         ([g2, g, g], [0, 1, 1]),          # back to identity through two steps
         ([g3, g, g2], [0, 1, 1]),         # 3P - P - 2P
         ([g] * 33, [0] * 33),
+        ([g] * 64, [0] * 64),             # tree: every level adds two equal accumulators (doubling path)
+        ([g, g2, g, g2], [0, 0, 1, 1]),   # tree: (P + 2P) + (-P - 2P) cancels at the top
+        ([g, g, g2, g3], [0, 0, 0, 1]),   # tree: 2P (by doubling) + (2P - 3P)
         ([g] * 6, [0, 1, 0, 1, 1, 0]),
     ]
     for plist, neg in cases:

@@ -166,15 +166,17 @@ def g1_sum_to_affine(xyz):
     return out, int(inf.value)
 
 
-def g1_bucket_selfcheck(xy, negate=None, infinity=None):
-    """Host-side run of the MSM kernels' bucket arithmetic -> (projective sum (18,), bound violations)."""
+def g1_bucket_selfcheck(xy, negate=None, infinity=None, tree=False):
+    """Host-side run of the MSM kernels' bucket arithmetic -> (projective sum (18,), bound violations); `tree` sums
+    accumulators pairwise as the bucket reduction does instead of adding the points one by one."""
     pts = _np_u64(xy, 12)
     n = pts.shape[0]
     neg = np.ascontiguousarray(negate if negate is not None else np.zeros(n), dtype=np.uint8)
     inf = np.ascontiguousarray(infinity if infinity is not None else np.zeros(n), dtype=np.uint8)
     out = np.zeros(18, dtype=np.uint64)
     viol = C.c_uint64(0)
-    rc = _lib.lib().zkgpu_g1_bucket_selfcheck(pts.ctypes.data if n else None, inf.ctypes.data if n else None,
+    fn = _lib.lib().zkgpu_g1_bucket_selfcheck_tree if tree else _lib.lib().zkgpu_g1_bucket_selfcheck
+    rc = fn(pts.ctypes.data if n else None, inf.ctypes.data if n else None,
                                               neg.ctypes.data if n else None, n, out.ctypes.data, C.addressof(viol))
     if rc != 0:
         raise ZkGpuError(rc, "g1_bucket_selfcheck")

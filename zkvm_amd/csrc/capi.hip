@@ -9,6 +9,7 @@
 #include "transcript.hpp"
 #include <cstring>
 #include <memory>
+#include <vector>
 #include <mutex>
 
 using namespace zk;
@@ -303,6 +304,30 @@ int zkgpu_g1_bucket_selfcheck(const uint64_t *xy, const uint8_t *infinity, const
         acc = xyzz_add_mixed(acc, affine_to_28(p), negate && negate[i]);
     }
     G1Proj r = xyzz_to_proj(acc);
+    memcpy(out_xyz, &r, sizeof r);
+    if (violations) *violations = (uint64_t)(fq28_violations() - before);
+    return ZKGPU_OK;
+}
+
+int zkgpu_g1_bucket_selfcheck_tree(const uint64_t *xy, const uint8_t *infinity, const uint8_t *negate, size_t n,
+                                   uint64_t out_xyz[18], uint64_t *violations) {
+    if ((!xy && n) || !out_xyz) return ZKGPU_ERR_INVALID_ARG;
+    const long before = fq28_violations();
+    std::vector<G1Xyzz> level(n ? n : 1, G1Xyzz::identity());
+    for (size_t i = 0; i < n; i++) {
+        G1Affine p;
+        memcpy(&p, xy + 12 * i, sizeof p);
+        if (infinity && infinity[i]) {
+            p.x = Fq::zero();
+            p.y = Fq::zero();
+        }
+        level[i] = xyzz_add_mixed(G1Xyzz::identity(), affine_to_28(p), negate && negate[i]);
+    }
+    for (size_t len = level.size(); len > 1; len = (len + 1) / 2) {
+        for (size_t i = 0; i < len / 2; i++) level[i] = xyzz_add(level[2 * i], level[2 * i + 1]);
+        if (len & 1) level[len / 2] = level[len - 1];
+    }
+    G1Proj r = xyzz_to_proj(level[0]);
     memcpy(out_xyz, &r, sizeof r);
     if (violations) *violations = (uint64_t)(fq28_violations() - before);
     return ZKGPU_OK;

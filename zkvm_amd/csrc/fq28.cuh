@@ -308,6 +308,55 @@ FF_HD G1Xyzz xyzz_add_mixed(const G1Xyzz &acc, const G1Affine28 &p, bool negate)
     return r;
 }
 
+// 2 * a for a non-identity accumulator: "dbl-2008-s-1"
+FF_HD G1Xyzz xyzz_double(const G1Xyzz &a) {
+    G1Xyzz r;
+    Fq28 u = Fq28::add(a.y, a.y);                // < 12p, limbs < 2^29
+    Fq28 v = m28(u, u);
+    Fq28 w = m28(u, v);
+    Fq28 s = m28(a.x, v);
+    Fq28 xx = m28(a.x, a.x);
+    Fq28 m = Fq28::add(Fq28::add(xx, xx), xx);   // < 6p, limbs < 3 * 2^28
+    Fq28 mm = m28(m, m);
+    Fq28 d = Fq28::sub4(Fq28::zero(), s);
+    r.x = Fq28::normalize(Fq28::add(mm, Fq28::add(d, d)));        // < 10p
+    Fq28 t = Fq28::sub16(s, r.x);
+    r.y = Fq28::normalize(Fq28::sub4(m28(m, t), m28(w, a.y)));    // < 6p
+    r.zz = m28(v, a.zz);
+    r.zzz = m28(w, a.zzz);
+    return r;
+}
+
+// a + b for two accumulators: "add-2008-s" (12 products + 2 squarings), exceptional cases resolved exactly
+FF_HD G1Xyzz xyzz_add(const G1Xyzz &a, const G1Xyzz &b) {
+    if (a.is_identity()) return b;
+    if (b.is_identity()) return a;
+    const Fq28 u1 = m28(a.x, b.zz);
+    const Fq28 u2 = m28(b.x, a.zz);
+    const Fq28 s1 = m28(a.y, b.zzz);
+    const Fq28 s2 = m28(b.y, a.zzz);
+    const Fq28 pd = Fq28::sub4(u2, u1);          // < 6p, limbs < 1.5 * 2^29
+    const Fq28 rd = Fq28::sub4(s2, s1);
+    const Fq28 pp = m28(pd, pd);
+    const Fq28 zz12 = m28(a.zz, b.zz);
+    const Fq28 zz3 = m28(zz12, pp);
+    if (zz3.is_zero_mod_p()) {
+        if (m28(rd, Fq28::one()).is_zero_mod_p()) return xyzz_double(a);
+        return G1Xyzz::identity();
+    }
+    const Fq28 ppp = m28(pd, pp);
+    const Fq28 q = m28(u1, pp);
+    const Fq28 rr = m28(rd, rd);
+    G1Xyzz r;
+    const Fq28 nq = Fq28::sub4(Fq28::zero(), q);
+    r.x = Fq28::normalize(Fq28::add(Fq28::sub4(rr, ppp), Fq28::add(nq, nq)));   // < 14p
+    const Fq28 t = Fq28::sub16(q, r.x);
+    r.y = Fq28::normalize(Fq28::sub4(m28(rd, t), m28(s1, ppp)));               // < 6p
+    r.zz = zz3;
+    r.zzz = m28(m28(a.zzz, b.zzz), ppp);
+    return r;
+}
+
 // The accumulator as a homogeneous projective point in the reference form: (X ZZZ : Y ZZ : ZZ ZZZ)
 FF_HD G1Proj xyzz_to_proj(const G1Xyzz &a) {
     if (a.is_identity()) return G1Proj::identity();

@@ -90,6 +90,37 @@ __device__ __forceinline__ void gstore_affine28(G1Affine28 *p, const G1Affine28 
 #pragma unroll
     for (int k = 0; k < 7; k++) q[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
 }
+__device__ __forceinline__ G1Xyzz gload_xyzz(const G1Xyzz *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint32_t w[56];
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        uint4 t = q[k];
+        w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w;
+    }
+    G1Xyzz r;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        r.x.v[k] = w[k];
+        r.y.v[k] = w[14 + k];
+        r.zz.v[k] = w[28 + k];
+        r.zzz.v[k] = w[42 + k];
+    }
+    return r;
+}
+__device__ __forceinline__ void gstore_xyzz(G1Xyzz *p, const G1Xyzz &a) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    uint32_t w[56];
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        w[k] = a.x.v[k];
+        w[14 + k] = a.y.v[k];
+        w[28 + k] = a.zz.v[k];
+        w[42 + k] = a.zzz.v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 14; k++) q[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
 __device__ __forceinline__ G1Proj gload_proj(const G1Proj *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
     G1Proj r;
@@ -310,7 +341,7 @@ __global__ void msm_schedule_scan_kernel(uint32_t *class_cursor) {
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const G1Affine28 *points, const uint32_t *sorted,
                                                              const uint32_t *offsets, const uint32_t *counts,
                                                              const uint32_t *order, const uint32_t *n_scheduled,
-                                                             G1Proj *buckets) {
+                                                             G1Xyzz *buckets) {
     uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= *n_scheduled) return;
     const uint32_t b = order[gid];
@@ -321,37 +352,40 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const G1Affine28 *p
         G1Affine28 p = gload_affine28(points + (v & 0x7fffffffu));
         acc = xyzz_add_mixed(acc, p, (v >> 31) != 0);
     }
-    gstore_proj(buckets + b, xyzz_to_proj(acc));
+    gstore_xyzz(buckets + b, acc);
 }
 
-__device__ __forceinline__ void lds_store_proj(uint32_t *sh, uint32_t slot, const G1Proj &p) {
-    uint32_t *d = sh + slot * 36;
+static const uint32_t TREE_LDS_WORDS = 128 * 56;   // 128 accumulators of 56 words
+__device__ __forceinline__ void lds_store_xyzz(uint32_t *sh, uint32_t slot, const G1Xyzz &p) {
+    uint32_t *d = sh + slot * 56;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
+    for (int i = 0; i < 14; i++) {
         d[i] = p.x.v[i];
-        d[12 + i] = p.y.v[i];
-        d[24 + i] = p.z.v[i];
+        d[14 + i] = p.y.v[i];
+        d[28 + i] = p.zz.v[i];
+        d[42 + i] = p.zzz.v[i];
     }
 }
-__device__ __forceinline__ G1Proj lds_load_proj(const uint32_t *sh, uint32_t slot) {
-    const uint32_t *d = sh + slot * 36;
-    G1Proj p;
+__device__ __forceinline__ G1Xyzz lds_load_xyzz(const uint32_t *sh, uint32_t slot) {
+    const uint32_t *d = sh + slot * 56;
+    G1Xyzz p;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
+    for (int i = 0; i < 14; i++) {
         p.x.v[i] = d[i];
-        p.y.v[i] = d[12 + i];
-        p.z.v[i] = d[24 + i];
+        p.y.v[i] = d[14 + i];
+        p.zz.v[i] = d[28 + i];
+        p.zzz.v[i] = d[42 + i];
     }
     return p;
 }
-// Sums the per-thread points of the first 2 * first_stride threads of a workgroup (the rest must hold the
+// Sums the per-thread accumulators of the first 2 * first_stride threads of a workgroup (the rest must hold the
 // identity or be beyond the data); the total is returned in thread 0.
-__device__ __forceinline__ G1Proj block_tree_sum(uint32_t *sh, G1Proj acc, uint32_t first_stride = 128) {
+__device__ __forceinline__ G1Xyzz block_tree_sum(uint32_t *sh, G1Xyzz acc, uint32_t first_stride = 128) {
     const uint32_t tid = threadIdx.x;
     for (uint32_t stride = first_stride; stride >= 1; stride >>= 1) {
-        if (tid >= stride && tid < 2 * stride) lds_store_proj(sh, tid - stride, acc);
+        if (tid >= stride && tid < 2 * stride) lds_store_xyzz(sh, tid - stride, acc);
         __syncthreads();
-        if (tid < stride) acc = g1_add(acc, lds_load_proj(sh, tid));
+        if (tid < stride) acc = xyzz_add(acc, lds_load_xyzz(sh, tid));
         __syncthreads();
     }
     return acc;
@@ -359,8 +393,8 @@ __device__ __forceinline__ G1Proj block_tree_sum(uint32_t *sh, G1Proj acc, uint3
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_big_partial_kernel(const G1Affine28 *points, const uint32_t *sorted,
                                                               const MsmTask *tasks, const uint32_t *task_count,
-                                                              uint32_t max_tasks, G1Proj *partials) {
-    __shared__ uint32_t sh[128 * 36];
+                                                              uint32_t max_tasks, G1Xyzz *partials) {
+    __shared__ uint32_t sh[TREE_LDS_WORDS];
     uint32_t n_tasks = *task_count;
     if (n_tasks > max_tasks) n_tasks = max_tasks;
     for (uint32_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
@@ -371,15 +405,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             G1Affine28 p = gload_affine28(points + (v & 0x7fffffffu));
             part = xyzz_add_mixed(part, p, (v >> 31) != 0);
         }
-        G1Proj acc = block_tree_sum(sh, xyzz_to_proj(part));
-        if (threadIdx.x == 0) gstore_proj(partials + t, acc);
+        part = block_tree_sum(sh, part);
+        if (threadIdx.x == 0) gstore_xyzz(partials + t, part);
     }
 }
 
 // One workgroup per oversized bucket: strided sums of its task partials, then the LDS tree.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_big_combine_kernel(const MsmTask *tasks, const uint32_t *task_count,
-                                                              uint32_t max_tasks, const G1Proj *partials, G1Proj *buckets) {
-    __shared__ uint32_t sh[128 * 36];
+                                                              uint32_t max_tasks, const G1Xyzz *partials, G1Xyzz *buckets) {
+    __shared__ uint32_t sh[TREE_LDS_WORDS];
     uint32_t n_tasks = *task_count;
     if (n_tasks > max_tasks) n_tasks = max_tasks;
     for (uint32_t t = blockIdx.x; t < n_tasks; t += gridDim.x) {
@@ -387,30 +421,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (!task.first) continue;  // uniform across the workgroup
         uint32_t cnt = task.first;
         if (t + cnt > n_tasks) cnt = n_tasks - t;
-        G1Proj acc = G1Proj::identity();
-        for (uint32_t k = threadIdx.x; k < cnt; k += 256) acc = g1_add(acc, gload_proj(partials + t + k));
+        G1Xyzz acc = G1Xyzz::identity();
+        for (uint32_t k = threadIdx.x; k < cnt; k += 256) acc = xyzz_add(acc, gload_xyzz(partials + t + k));
         acc = block_tree_sum(sh, acc);
-        if (threadIdx.x == 0) gstore_proj(buckets + task.key, acc);
+        if (threadIdx.x == 0) gstore_xyzz(buckets + task.key, acc);
     }
 }
 
 // ---- bucket reduction -------------------------------------------------------------------------------------
 // Level 1: one thread per segment s of L = 2^log_seg buckets: T_s = sum_j bucket[sL + j] and
 // W_s = sum_j j * bucket[sL + j] by running sums from the top.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_segment_kernel(const G1Proj *buckets, uint32_t log_seg, uint32_t n_segments,
-                                                          G1Proj *t_out, G1Proj *w_out) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_segment_kernel(const G1Xyzz *buckets, uint32_t log_seg, uint32_t n_segments,
+                                                          G1Xyzz *t_out, G1Xyzz *w_out) {
     uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n_segments) return;
     const uint32_t seg = 1u << log_seg;
-    const G1Proj *bp = buckets + ((size_t)gid << log_seg);
-    G1Proj run = G1Proj::identity(), acc = G1Proj::identity();
+    const G1Xyzz *bp = buckets + ((size_t)gid << log_seg);
+    G1Xyzz run = G1Xyzz::identity(), acc = G1Xyzz::identity();
     for (int r = (int)seg - 1; r >= 1; r--) {
-        run = g1_add(run, gload_proj(bp + r));
-        acc = g1_add(acc, run);
+        run = xyzz_add(run, gload_xyzz(bp + r));
+        acc = xyzz_add(acc, run);
     }
-    run = g1_add(run, gload_proj(bp));
-    gstore_proj(t_out + gid, run);
-    gstore_proj(w_out + gid, acc);
+    run = xyzz_add(run, gload_xyzz(bp));
+    gstore_xyzz(t_out + gid, run);
+    gstore_xyzz(w_out + gid, acc);
 }
 
 // Level 2: equally sized groups of n_segments / 2 elements each, so that every workgroup carries the same work:
@@ -419,12 +453,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 //   g = n_bits + 1/2 the lower / upper half of the W_s
 // With a single segment (n_bits = 0) there are two groups of one element: T_0 and W_0.
 // grid = (blocks per group, groups); each block leaves one partial sum.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_group_partial_kernel(const G1Proj *t_in, const G1Proj *w_in, uint32_t n_segments,
-                                                                uint32_t n_bits, G1Proj *partials) {
-    __shared__ uint32_t sh[128 * 36];
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_group_partial_kernel(const G1Xyzz *t_in, const G1Xyzz *w_in, uint32_t n_segments,
+                                                                uint32_t n_bits, G1Xyzz *partials) {
+    __shared__ uint32_t sh[TREE_LDS_WORDS];
     const uint32_t g = blockIdx.y;
     const uint32_t count = n_bits ? (n_segments >> 1) : 1u;
-    const G1Proj *src = t_in;
+    const G1Xyzz *src = t_in;
     uint32_t k = g, set = 1u, offset = 0;
     if (n_bits == 0) {
         if (g == 1) src = w_in;
@@ -437,26 +471,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         k = 0xffffffffu;
         offset = (g - n_bits - 1) * count;
     }
-    G1Proj acc = G1Proj::identity();
+    G1Xyzz acc = G1Xyzz::identity();
     for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < count; j += gridDim.x * 256) {
         uint32_t e = j + offset;
         if (k != 0xffffffffu) e = ((j >> k) << (k + 1)) | (set << k) | (j & ((1u << k) - 1u));   // j-th index with bit k set/clear
-        acc = g1_add(acc, gload_proj(src + e));
+        acc = xyzz_add(acc, gload_xyzz(src + e));
     }
     acc = block_tree_sum(sh, acc);
-    if (threadIdx.x == 0) gstore_proj(partials + (size_t)g * gridDim.x + blockIdx.x, acc);
+    if (threadIdx.x == 0) gstore_xyzz(partials + (size_t)g * gridDim.x + blockIdx.x, acc);
 }
 
 // Level 3: one workgroup per group adds that group's partial sums.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_group_final_kernel(const G1Proj *partials, uint32_t per_group, G1Proj *out) {
-    __shared__ uint32_t sh[128 * 36];
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_group_final_kernel(const G1Xyzz *partials, uint32_t per_group, G1Proj *out) {
+    __shared__ uint32_t sh[TREE_LDS_WORDS];
     const uint32_t g = blockIdx.x;
-    G1Proj acc = G1Proj::identity();
-    for (uint32_t k = threadIdx.x; k < per_group; k += 256) acc = g1_add(acc, gload_proj(partials + (size_t)g * per_group + k));
+    G1Xyzz acc = G1Xyzz::identity();
+    for (uint32_t k = threadIdx.x; k < per_group; k += 256) acc = xyzz_add(acc, gload_xyzz(partials + (size_t)g * per_group + k));
     uint32_t first = 128;
     while (first > 1 && first >= per_group) first >>= 1;   // threads >= per_group hold the identity
     acc = block_tree_sum(sh, acc, first);
-    if (threadIdx.x == 0) gstore_proj(out + g, acc);
+    if (threadIdx.x == 0) gstore_proj(out + g, xyzz_to_proj(acc));
 }
 
 // ---- table of window multiples ----------------------------------------------------------------------------
@@ -666,16 +700,16 @@ void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_
     digits_.reserve(n_items64 * 4);
     block_sums_.reserve((size_t)n_scan_blocks * 4 + 4);
     sorted_.reserve(n_items64 * 4);
-    buckets_.reserve((size_t)B * sizeof(G1Proj));
+    buckets_.reserve((size_t)B * sizeof(G1Xyzz));
     tasks_.reserve((size_t)max_tasks * sizeof(MsmTask) + 16);
     const size_t group_partials = (size_t)groups * blocks_per_group;
-    partials_.reserve((max_tasks > group_partials ? max_tasks : group_partials) * sizeof(G1Proj));
-    seg_.reserve((size_t)2 * n_segments * sizeof(G1Proj));
+    partials_.reserve((max_tasks > group_partials ? max_tasks : group_partials) * sizeof(G1Xyzz));
+    seg_.reserve((size_t)2 * n_segments * sizeof(G1Xyzz));
     group_sums_.reserve((size_t)groups * sizeof(G1Proj));
     uint32_t *task_count = reinterpret_cast<uint32_t *>(tasks_.as<char>() + (size_t)max_tasks * sizeof(MsmTask));
     uint32_t *order = order_.as<uint32_t>();
     uint32_t *class_cursor = order + B;
-    G1Proj *t_seg = seg_.as<G1Proj>(), *w_seg = t_seg + n_segments;
+    G1Xyzz *t_seg = seg_.as<G1Xyzz>(), *w_seg = t_seg + n_segments;
 
     const G1Affine28 *table = table28_.as<G1Affine28>();
     ZK_HIP(hipMemsetAsync(task_count, 0, 4, stream_));
@@ -703,18 +737,18 @@ void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_
     hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
                        class_shift, class_cursor, order);
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, table, sorted_.as<uint32_t>(),
-                       offsets_.as<uint32_t>(), counts_.as<uint32_t>(), order, class_cursor + N_CLASSES, buckets_.as<G1Proj>());
+                       offsets_.as<uint32_t>(), counts_.as<uint32_t>(), order, class_cursor + N_CLASSES, buckets_.as<G1Xyzz>());
     const uint32_t big_grid = max_tasks < 2048 ? max_tasks : 2048;
     hipLaunchKernelGGL(msm_big_partial_kernel, dim3(big_grid), dim3(256), 0, stream_, table, sorted_.as<uint32_t>(),
-                       tasks_.as<MsmTask>(), task_count, max_tasks, partials_.as<G1Proj>());
+                       tasks_.as<MsmTask>(), task_count, max_tasks, partials_.as<G1Xyzz>());
     hipLaunchKernelGGL(msm_big_combine_kernel, dim3(big_grid), dim3(256), 0, stream_, tasks_.as<MsmTask>(), task_count,
-                       max_tasks, partials_.as<G1Proj>(), buckets_.as<G1Proj>());
+                       max_tasks, partials_.as<G1Xyzz>(), buckets_.as<G1Xyzz>());
     // reduction (partials_ is free again: the oversized-bucket kernels above have consumed it in stream order)
-    hipLaunchKernelGGL(msm_segment_kernel, dim3(ceil_div(n_segments, 256)), dim3(256), 0, stream_, buckets_.as<G1Proj>(), log_seg,
+    hipLaunchKernelGGL(msm_segment_kernel, dim3(ceil_div(n_segments, 256)), dim3(256), 0, stream_, buckets_.as<G1Xyzz>(), log_seg,
                        n_segments, t_seg, w_seg);
     hipLaunchKernelGGL(msm_group_partial_kernel, dim3(blocks_per_group, groups), dim3(256), 0, stream_, t_seg, w_seg, n_segments,
-                       n_bits, partials_.as<G1Proj>());
-    hipLaunchKernelGGL(msm_group_final_kernel, dim3(groups), dim3(256), 0, stream_, partials_.as<G1Proj>(), blocks_per_group,
+                       n_bits, partials_.as<G1Xyzz>());
+    hipLaunchKernelGGL(msm_group_final_kernel, dim3(groups), dim3(256), 0, stream_, partials_.as<G1Xyzz>(), blocks_per_group,
                        group_sums_.as<G1Proj>());
     ZK_HIP(hipGetLastError());
     n_groups = groups;

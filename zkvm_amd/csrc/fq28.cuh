@@ -232,8 +232,11 @@ inline long &fq28_violations() {
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-static __device__ __noinline__ Fq28 fq28_mul_outlined(Fq28 a, Fq28 b) { return Fq28::mul(a, b); }
-__device__ __forceinline__ Fq28 m28(const Fq28 &a, const Fq28 &b) { return fq28_mul_outlined(a, b); }
+// Inlined on purpose: at ~510 instructions a product is small enough for the whole mixed addition (10 of them) to
+// stay inside the instruction cache, and a call would move 28 operand registers and pin the register allocation
+// (measured: 161 VGPRs / 3 waves per SIMD inlined against 209 VGPRs + spills / 2 waves outlined, 24% faster MSM).
+static __device__ __forceinline__ Fq28 fq28_mul_inlined(const Fq28 &a, const Fq28 &b) { return Fq28::mul(a, b); }
+__device__ __forceinline__ Fq28 m28(const Fq28 &a, const Fq28 &b) { return fq28_mul_inlined(a, b); }
 #else
 // Host build: every product checks the preconditions of Fq28::mul and counts violations, so that the host-side
 // self-check of the bucket arithmetic also proves the limb and magnitude bounds on the inputs it sees.

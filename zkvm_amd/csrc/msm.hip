@@ -178,16 +178,26 @@ __global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t *dig, Sor
     const uint32_t lo = s * g.slice;
     uint32_t hi = lo + g.slice;
     if (hi > g.n_items || hi < lo) hi = g.n_items;
-    for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
-        uint32_t v = dig[j];
-        uint32_t mag = v & 0x7fffffffu;
-        if (!mag) continue;
-        uint32_t b = mag - 1;
-        if ((b >> g.log_range) != r) continue;
-        uint32_t pos = atomicAdd(&hist[b & (range - 1)], 1u);
-        if (PASS) {
-            uint32_t w = j / g.n, i = j - w * g.n;
-            sorted[pos] = (w * g.stride + g.base + i) | (v & 0x80000000u);
+    // four independent loads in flight per thread: the scan is bound by L2 latency, not by bandwidth
+    for (uint32_t j0 = lo + threadIdx.x; j0 < hi; j0 += 4 * blockDim.x) {
+        uint32_t vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t j = j0 + u * blockDim.x;
+            vv[u] = j < hi ? dig[j] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t j = j0 + u * blockDim.x, v = vv[u];
+            uint32_t mag = v & 0x7fffffffu;
+            if (!mag) continue;
+            uint32_t b = mag - 1;
+            if ((b >> g.log_range) != r) continue;
+            uint32_t pos = atomicAdd(&hist[b & (range - 1)], 1u);
+            if (PASS) {
+                uint32_t w = j / g.n, i = j - w * g.n;
+                sorted[pos] = (w * g.stride + g.base + i) | (v & 0x80000000u);
+            }
         }
     }
     if (!PASS) {

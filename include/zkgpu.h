@@ -124,6 +124,10 @@ int zkgpu_msm_kernels_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n);
  * Polynomial::degree does).  ZKGPU_ERR_DEGREE_ZERO / ZKGPU_ERR_DEGREE_LARGE mirror the reference's errors. */
 int zkgpu_commit(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, uint64_t out_xy[12], uint8_t *out_infinity);
 
+/* Host-only self-check of the Montgomery product the kernels are built on (the same source compiles for host and
+ * device): field 0 = Fr (4 limbs per element), 1 = Fq (6 limbs); out[i] = a[i] * b[i] for count elements. */
+int zkgpu_field_mul_selfcheck(int field, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out);
+
 /* Host-only self-check of the bucket arithmetic used inside the MSM kernels (28-bit unsaturated limbs, extended
  * Jacobian mixed additions): adds the n affine points in order, point i negated when negate[i] != 0, and returns the
  * sum as a projective point.  *violations receives the number of products whose operands broke the limb or

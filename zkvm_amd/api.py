@@ -166,6 +166,17 @@ def g1_sum_to_affine(xyz):
     return out, int(inf.value)
 
 
+def field_mul_selfcheck(field, a, b):
+    """Host-side run of the kernels' Montgomery product: field 0 = Fr (n, 4), 1 = Fq (n, 6)."""
+    width = 4 if field == 0 else 6
+    x, y = _np_u64(a, width), _np_u64(b, width)
+    out = np.zeros_like(x)
+    rc = _lib.lib().zkgpu_field_mul_selfcheck(int(field), x.ctypes.data, y.ctypes.data, x.shape[0], out.ctypes.data)
+    if rc != 0:
+        raise ZkGpuError(rc, "field_mul_selfcheck")
+    return out
+
+
 def g1_bucket_selfcheck(xy, negate=None, infinity=None, tree=False):
     """Host-side run of the MSM kernels' bucket arithmetic -> (projective sum (18,), bound violations); `tree` sums
     accumulators pairwise as the bucket reduction does instead of adding the points one by one."""

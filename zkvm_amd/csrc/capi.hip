@@ -289,6 +289,26 @@ int zkgpu_commit(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, uint64_t ou
     });
 }
 
+int zkgpu_field_mul_selfcheck(int field, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out) {
+    if ((field != 0 && field != 1) || ((!a || !b || !out) && count)) return ZKGPU_ERR_INVALID_ARG;
+    for (size_t i = 0; i < count; i++) {
+        if (field == 0) {
+            Fr x, y;
+            memcpy(&x, a + 4 * i, sizeof x);
+            memcpy(&y, b + 4 * i, sizeof y);
+            Fr z = Fr::mul(x, y);
+            memcpy(out + 4 * i, &z, sizeof z);
+        } else {
+            Fq x, y;
+            memcpy(&x, a + 6 * i, sizeof x);
+            memcpy(&y, b + 6 * i, sizeof y);
+            Fq z = Fq::mul(x, y);
+            memcpy(out + 6 * i, &z, sizeof z);
+        }
+    }
+    return ZKGPU_OK;
+}
+
 int zkgpu_g1_bucket_selfcheck(const uint64_t *xy, const uint8_t *infinity, const uint8_t *negate, size_t n,
                               uint64_t out_xyz[18], uint64_t *violations) {
     if ((!xy && n) || !out_xyz) return ZKGPU_ERR_INVALID_ARG;

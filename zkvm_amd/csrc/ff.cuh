@@ -151,33 +151,71 @@ struct Fp_ {
     }
     FF_HD static Fp_ dbl(const Fp_ &a) { return add(a, a); }
 
-    // Montgomery product a*b*R^-1 mod p, canonical.
+    // ---- Montgomery product a*b*R^-1 mod p, canonical ---------------------------------------------------------
+    // Computed on unsaturated limbs: UN limbs of UL bits (9 x 29 for Fr, 14 x 28 for Fq).  A column of UN + UN
+    // partial products then fits one 64-bit accumulator, so every product is a single v_mad_u64_u32 with no carry
+    // instruction behind it (the 32-bit-limb form needs an add-with-carry per product).  The wider radix
+    // 2^(UL*UN) = R * 2^USH is compensated by taking b * 2^USH while it is unpacked: a * (b 2^USH) / 2^(UL*UN) =
+    // a b / R exactly, below 2p, and one conditional subtraction makes it canonical again.
+    FF_HD static uint32_t unpack_limb(const Fp_ &x, int start) {   // bits [start, start + UL) of x, zero outside
+        constexpr uint32_t MASK = (1u << P::UL) - 1u;
+        if (start < 0) return (x.v[0] << (-start)) & MASK;
+        const int w = start >> 5, s = start & 31;
+        uint32_t lo = w < N ? x.v[w] >> s : 0u;
+        if (s + P::UL > 32 && w + 1 < N) lo |= x.v[w + 1] << (32 - s);
+        return lo & MASK;
+    }
     FF_HD static Fp_ mul(const Fp_ &a, const Fp_ &b) {
-        uint32_t m[N];
-        Fp_ r;
-        Acc96 c;
-        c.lh = 0;
-        c.ex = 0;
+        constexpr int UL = P::UL, UN = P::UN;
+        constexpr uint32_t MASK = (1u << UL) - 1u;
+        uint32_t x[UN], y[UN], m[UN], r[UN];
 #pragma unroll
-        for (int k = 0; k < N; k++) {
+        for (int i = 0; i < UN; i++) {
+            x[i] = unpack_limb(a, UL * i);
+            y[i] = unpack_limb(b, UL * i - P::USH);
+        }
+        uint64_t c = 0;
 #pragma unroll
-            for (int i = 0; i <= k; i++) acc_mac(c, a.v[i], b.v[k - i]);
+        for (int k = 0; k < UN; k++) {
 #pragma unroll
-            for (int i = 0; i < k; i++) acc_mac(c, m[i], P::mod(k - i));
-            m[k] = (uint32_t)c.lh * P::INV32;
-            acc_mac(c, m[k], P::mod(0));
-            (void)acc_shift(c);
+            for (int i = 0; i <= k; i++) c += (uint64_t)x[i] * y[k - i];
+#pragma unroll
+            for (int i = 0; i < k; i++) c += (uint64_t)m[i] * P::umod(k - i);
+            m[k] = ((uint32_t)c * P::UINV) & MASK;
+            c += (uint64_t)m[k] * P::umod(0);
+            c >>= UL;
         }
 #pragma unroll
-        for (int k = N; k < 2 * N - 1; k++) {
+        for (int k = UN; k < 2 * UN - 1; k++) {
 #pragma unroll
-            for (int i = k - N + 1; i < N; i++) acc_mac(c, a.v[i], b.v[k - i]);
+            for (int i = k - UN + 1; i < UN; i++) c += (uint64_t)x[i] * y[k - i];
 #pragma unroll
-            for (int i = k - N + 1; i < N; i++) acc_mac(c, m[i], P::mod(k - i));
-            r.v[k - N] = acc_shift(c);
+            for (int i = k - UN + 1; i < UN; i++) c += (uint64_t)m[i] * P::umod(k - i);
+            r[k - UN] = (uint32_t)c & MASK;
+            c >>= UL;
         }
-        r.v[N - 1] = (uint32_t)c.lh;
-        return reduce_once(r);
+        r[UN - 1] = (uint32_t)c;
+        // r < 2p: subtract p once if r >= p
+        uint32_t d[UN], borrow = 0;
+#pragma unroll
+        for (int i = 0; i < UN; i++) {
+            uint32_t t = r[i] - P::umod(i) - borrow;
+            borrow = t >> 31;
+            d[i] = t & MASK;
+        }
+#pragma unroll
+        for (int i = 0; i < UN; i++) r[i] = borrow ? r[i] : d[i];
+        // back to 32-bit words
+        Fp_ o;
+#pragma unroll
+        for (int w = 0; w < N; w++) {
+            const int bit = 32 * w, i = bit / UL, s = bit - UL * i;
+            uint32_t lo = r[i] >> s;
+            if (i + 1 < UN) lo |= r[i + 1] << (UL - s);
+            if (2 * UL - s < 32 && i + 2 < UN) lo |= r[i + 2] << (2 * UL - s);
+            o.v[w] = lo;
+        }
+        return o;
     }
     FF_HD static Fp_ sqr(const Fp_ &a) { return mul(a, a); }
 
@@ -236,6 +274,14 @@ struct Fp_ {
 struct FrParams {
     static constexpr int N = 8;
     static constexpr uint32_t INV32 = 0xffffffffu;
+    // unsaturated form used inside mul: 9 limbs of 29 bits, radix 2^261 = 2^256 * 2^5
+    static constexpr int UL = 29, UN = 9, USH = 5;
+    static constexpr uint32_t UINV = 0x1fffffffu;   // -r^-1 mod 2^29
+    FF_HD static uint32_t umod(int i) {
+        constexpr uint32_t M[9] = {0x00000001u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu,
+                                   0x0c0404d0u, 0x1520cce7u, 0x0a6533afu, 0x0073eda7u};
+        return M[i];
+    }
     FF_HD static uint32_t mod(int i) {
         constexpr uint32_t M[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
                                    0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
@@ -256,6 +302,14 @@ struct FrParams {
 struct FqParams {
     static constexpr int N = 12;
     static constexpr uint32_t INV32 = 0xfffcfffdu;
+    // unsaturated form used inside mul: 14 limbs of 28 bits, radix 2^392 = 2^384 * 2^8
+    static constexpr int UL = 28, UN = 14, USH = 8;
+    static constexpr uint32_t UINV = 0x0ffcfffdu;   // -p^-1 mod 2^28
+    FF_HD static uint32_t umod(int i) {
+        constexpr uint32_t M[14] = {0xfffaaabu, 0xfefffffu, 0x3ffffb9u, 0xfffeb15u, 0x6241eabu, 0xa0f6b0fu, 0xf6730d2u,
+                                    0xf38512bu, 0x4774b84u, 0x4bacd76u, 0xba7b643u, 0xe69a4b1u, 0x1ea397fu, 0x001a011u};
+        return M[i];
+    }
     FF_HD static uint32_t mod(int i) {
         constexpr uint32_t M[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
                                     0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};

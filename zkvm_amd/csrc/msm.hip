@@ -466,7 +466,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_group_partial_kernel(const G1Xyzz *t_in, const G1Xyzz *w_in, uint32_t n_segments,
                                                                 uint32_t n_bits, G1Xyzz *partials) {
     __shared__ uint32_t sh[TREE_LDS_WORDS];
-    const uint32_t g = blockIdx.y;
+    const uint32_t g = blockIdx.y, sum = blockIdx.z;   // n_segments = segments per sum
+    t_in += (size_t)sum * n_segments;
+    w_in += (size_t)sum * n_segments;
     const uint32_t count = n_bits ? (n_segments >> 1) : 1u;
     const G1Xyzz *src = t_in;
     uint32_t k = g, set = 1u, offset = 0;
@@ -488,7 +490,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         acc = xyzz_add(acc, gload_xyzz(src + e));
     }
     acc = block_tree_sum(sh, acc);
-    if (threadIdx.x == 0) gstore_xyzz(partials + (size_t)g * gridDim.x + blockIdx.x, acc);
+    if (threadIdx.x == 0) gstore_xyzz(partials + ((size_t)sum * gridDim.y + g) * gridDim.x + blockIdx.x, acc);
 }
 
 // Level 3: one workgroup per group adds that group's partial sums.
@@ -656,44 +658,40 @@ void MsmEngine::load_points_device(const void *xy_dev, size_t n) {
     build_table(n);
 }
 
-void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_t &n_groups, uint32_t &log_seg_out) {
-    ZK_REQUIRE(base + n <= n_points_, ZKGPU_ERR_INVALID_ARG, "msm: more scalars than loaded points");
-    ZK_REQUIRE(n >= 1 && n < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "msm: bad length");
+void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const size_t *lens, size_t base,
+                                 uint32_t &n_groups, uint32_t &log_seg_out) {
+    ZK_REQUIRE(m >= 1 && m <= MAX_BATCH, ZKGPU_ERR_INVALID_ARG, "msm: batch size out of range");
     const uint32_t c = c_, K = K_;
     const uint32_t log_B = c - 1, B = 1u << log_B;
-    const uint64_t n_items64 = (uint64_t)n * K;
-    ZK_REQUIRE(n_items64 < (1ull << 32) - 2048, ZKGPU_ERR_INVALID_ARG, "msm: too many (point, window) pairs for 32-bit offsets");
-    const uint32_t n_items = (uint32_t)n_items64;
+    const uint32_t nb = m * B;   // bucket j * B + b belongs to sum j
+    uint64_t total_items = 0, max_items = 0;
+    for (uint32_t j = 0; j < m; j++) {
+        ZK_REQUIRE(base + lens[j] <= n_points_, ZKGPU_ERR_INVALID_ARG, "msm: more scalars than loaded points");
+        ZK_REQUIRE(lens[j] >= 1 && lens[j] < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "msm: bad length");
+        total_items += (uint64_t)lens[j] * K;
+        if ((uint64_t)lens[j] * K > max_items) max_items = (uint64_t)lens[j] * K;
+    }
+    ZK_REQUIRE(total_items < (1ull << 32) - 2048, ZKGPU_ERR_INVALID_ARG, "msm: too many (point, window) pairs for 32-bit offsets");
     uint32_t class_shift = 0;   // oversize threshold = 256 << shift >= four times the mean bucket size
-    while (((uint64_t)BIG_BUCKET << class_shift) < 4 * (n_items64 >> log_B) && class_shift < 12) class_shift++;
+    while (((uint64_t)BIG_BUCKET << class_shift) < 4 * (max_items >> log_B) && class_shift < 12) class_shift++;
     const uint32_t big = BIG_BUCKET << class_shift;
-    const uint32_t max_tasks = (uint32_t)(n_items64 / big + 1);
-    const uint32_t n_scan_blocks = ceil_div(B, SCAN_ITEMS);
+    const uint32_t max_tasks = (uint32_t)(total_items / big + m);
+    const uint32_t n_scan_blocks = ceil_div(nb, SCAN_ITEMS);
     const uint32_t log_seg = log_B < seg_bits_ ? log_B : seg_bits_;
-    const uint32_t n_segments = 1u << (log_B - log_seg);
+    const uint32_t segs_per_sum = 1u << (log_B - log_seg);
     const uint32_t n_bits = log_B - log_seg;
     const uint32_t groups = n_bits ? n_bits + 3 : 2;
     // two resident workgroups per CU run these latency-bound sums in a single round: ~512 workgroups in total
-    uint32_t blocks_per_group = 512 / groups;
-    const uint32_t max_useful = ceil_div(n_bits ? n_segments / 2 : 1, 256);
+    uint32_t blocks_per_group = 512 / (groups * m);
+    const uint32_t max_useful = ceil_div(n_bits ? segs_per_sum / 2 : 1, 256);
     if (blocks_per_group > max_useful) blocks_per_group = max_useful;
     if (blocks_per_group < 1) blocks_per_group = 1;
 
     // sort geometry: bucket ranges of at most 2^15 (128 KiB of LDS counters), slices so that ~1024 workgroups exist
     const uint32_t log_range = log_B < 15 ? log_B : 15;
     const uint32_t n_ranges = 1u << (log_B - log_range);
-    uint32_t S = 1024 / n_ranges;
-    if (S < 1) S = 1;
-    while (S > 1 && n_items / S < 8192) S >>= 1;  // keep slices long enough to amortise the histogram flush
-    SortGeom geom;
-    geom.n_items = n_items;
-    geom.n = (uint32_t)n;
-    geom.stride = (uint32_t)n_points_;
-    geom.base = (uint32_t)base;
-    geom.B = B;
-    geom.log_range = log_range;
-    geom.S = S;
-    geom.slice = (uint32_t)((n_items64 + S - 1) / S);
+    uint32_t S_max = 1024 / n_ranges;
+    if (S_max < 1) S_max = 1;
     const size_t lds_bytes = (size_t)4 << log_range;
     if (!lds_attr_set_) {
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort_kernel<0>),
@@ -703,90 +701,138 @@ void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_
         lds_attr_set_ = true;
     }
 
-    counts_.reserve((size_t)B * 4);
-    offsets_.reserve((size_t)B * 4);
-    cursor_.reserve((size_t)B * S * 4);                 // per-(slice, bucket) counts, then cursors
-    order_.reserve((size_t)B * 4 + (N_CLASSES + 1) * 4);
-    digits_.reserve(n_items64 * 4);
+    counts_.reserve((size_t)nb * 4);
+    offsets_.reserve((size_t)nb * 4);
+    cursor_.reserve((size_t)nb * S_max * 4);            // per-(sum, slice, bucket) counts, then cursors
+    order_.reserve((size_t)nb * 4 + (N_CLASSES + 1) * 4);
+    digits_.reserve(total_items * 4);
     block_sums_.reserve((size_t)n_scan_blocks * 4 + 4);
-    sorted_.reserve(n_items64 * 4);
-    buckets_.reserve((size_t)B * sizeof(G1Xyzz));
+    sorted_.reserve(total_items * 4);
+    buckets_.reserve((size_t)nb * sizeof(G1Xyzz));
     tasks_.reserve((size_t)max_tasks * sizeof(MsmTask) + 16);
-    const size_t group_partials = (size_t)groups * blocks_per_group;
+    const size_t group_partials = (size_t)m * groups * blocks_per_group;
     partials_.reserve((max_tasks > group_partials ? max_tasks : group_partials) * sizeof(G1Xyzz));
-    seg_.reserve((size_t)2 * n_segments * sizeof(G1Xyzz));
-    group_sums_.reserve((size_t)groups * sizeof(G1Proj));
+    seg_.reserve((size_t)2 * m * segs_per_sum * sizeof(G1Xyzz));
+    group_sums_.reserve((size_t)m * groups * sizeof(G1Proj));
     uint32_t *task_count = reinterpret_cast<uint32_t *>(tasks_.as<char>() + (size_t)max_tasks * sizeof(MsmTask));
     uint32_t *order = order_.as<uint32_t>();
-    uint32_t *class_cursor = order + B;
+    uint32_t *class_cursor = order + nb;
+    const uint32_t n_segments = m * segs_per_sum;
     G1Xyzz *t_seg = seg_.as<G1Xyzz>(), *w_seg = t_seg + n_segments;
 
     const G1Affine28 *table = table28_.as<G1Affine28>();
     ZK_HIP(hipMemsetAsync(task_count, 0, 4, stream_));
     ZK_HIP(hipMemsetAsync(class_cursor, 0, (N_CLASSES + 1) * 4, stream_));
-    hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, scalars_dev, (uint32_t)n, c, K,
-                       digits_.as<uint32_t>());
-    const dim3 sort_grid(S, n_ranges);
-    hipLaunchKernelGGL(msm_sort_kernel<0>, sort_grid, dim3(1024), lds_bytes, stream_, digits_.as<uint32_t>(), geom,
-                       cursor_.as<uint32_t>(), sorted_.as<uint32_t>());
-    hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, cursor_.as<uint32_t>(), B, S,
-                       counts_.as<uint32_t>());
+
+    // per sum: digits and the count pass of its own items into its own B counters
+    SortGeom geom[MAX_BATCH];
+    uint32_t *dig[MAX_BATCH];
+    uint64_t item_base = 0;
+    for (uint32_t j = 0; j < m; j++) {
+        const uint64_t n_items = (uint64_t)lens[j] * K;
+        uint32_t S = S_max;
+        while (S > 1 && n_items / S < 8192) S >>= 1;  // keep slices long enough to amortise the histogram flush
+        geom[j].n_items = (uint32_t)n_items;
+        geom[j].n = (uint32_t)lens[j];
+        geom[j].stride = (uint32_t)n_points_;
+        geom[j].base = (uint32_t)base;
+        geom[j].B = B;
+        geom[j].log_range = log_range;
+        geom[j].S = S;
+        geom[j].slice = (uint32_t)((n_items + S - 1) / S);
+        dig[j] = digits_.as<uint32_t>() + item_base;
+        item_base += n_items;
+        uint32_t *part = cursor_.as<uint32_t>() + (size_t)j * B * S_max;
+        hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(lens[j], 256)), dim3(256), 0, stream_, scalars_dev[j],
+                           (uint32_t)lens[j], c, K, dig[j]);
+        hipLaunchKernelGGL(msm_sort_kernel<0>, dim3(S, n_ranges), dim3(1024), lds_bytes, stream_, dig[j], geom[j], part,
+                           sorted_.as<uint32_t>());
+        hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, part, B, S,
+                           counts_.as<uint32_t>() + (size_t)j * B);
+    }
+    // one scan over all m * B buckets: every bucket's run in `sorted`
     hipLaunchKernelGGL(scan_block_kernel, dim3(n_scan_blocks), dim3(256), 0, stream_, counts_.as<uint32_t>(),
-                       offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), B);
+                       offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream_, block_sums_.as<uint32_t>(), n_scan_blocks);
-    hipLaunchKernelGGL(scan_finish_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, counts_.as<uint32_t>(),
-                       offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), B, big, tasks_.as<MsmTask>(), task_count, max_tasks);
-    hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, cursor_.as<uint32_t>(),
-                       offsets_.as<uint32_t>(), B, S);
-    hipLaunchKernelGGL(msm_sort_kernel<1>, sort_grid, dim3(1024), lds_bytes, stream_, digits_.as<uint32_t>(), geom,
-                       cursor_.as<uint32_t>(), sorted_.as<uint32_t>());
+    hipLaunchKernelGGL(scan_finish_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, counts_.as<uint32_t>(),
+                       offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb, big, tasks_.as<MsmTask>(), task_count, max_tasks);
+    for (uint32_t j = 0; j < m; j++) {
+        uint32_t *part = cursor_.as<uint32_t>() + (size_t)j * B * S_max;
+        hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, part,
+                           offsets_.as<uint32_t>() + (size_t)j * B, B, geom[j].S);
+        hipLaunchKernelGGL(msm_sort_kernel<1>, dim3(geom[j].S, n_ranges), dim3(1024), lds_bytes, stream_, dig[j], geom[j], part,
+                           sorted_.as<uint32_t>());
+    }
     // schedule: class histogram, scan, placement
-    hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
+    hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(nb, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), nb,
                        class_shift, class_cursor, order);
     hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(1), dim3(64), 0, stream_, class_cursor);
-    hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
+    hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(nb, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), nb,
                        class_shift, class_cursor, order);
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, table, sorted_.as<uint32_t>(),
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, table, sorted_.as<uint32_t>(),
                        offsets_.as<uint32_t>(), counts_.as<uint32_t>(), order, class_cursor + N_CLASSES, buckets_.as<G1Xyzz>());
     const uint32_t big_grid = max_tasks < 2048 ? max_tasks : 2048;
     hipLaunchKernelGGL(msm_big_partial_kernel, dim3(big_grid), dim3(256), 0, stream_, table, sorted_.as<uint32_t>(),
                        tasks_.as<MsmTask>(), task_count, max_tasks, partials_.as<G1Xyzz>());
     hipLaunchKernelGGL(msm_big_combine_kernel, dim3(big_grid), dim3(256), 0, stream_, tasks_.as<MsmTask>(), task_count,
                        max_tasks, partials_.as<G1Xyzz>(), buckets_.as<G1Xyzz>());
-    // reduction (partials_ is free again: the oversized-bucket kernels above have consumed it in stream order)
+    // reduction of all sums together (partials_ is free again: the oversized-bucket kernels above have consumed it in
+    // stream order); the segments of sum j are [j * segs_per_sum, (j + 1) * segs_per_sum)
     hipLaunchKernelGGL(msm_segment_kernel, dim3(ceil_div(n_segments, 256)), dim3(256), 0, stream_, buckets_.as<G1Xyzz>(), log_seg,
                        n_segments, t_seg, w_seg);
-    hipLaunchKernelGGL(msm_group_partial_kernel, dim3(blocks_per_group, groups), dim3(256), 0, stream_, t_seg, w_seg, n_segments,
-                       n_bits, partials_.as<G1Xyzz>());
-    hipLaunchKernelGGL(msm_group_final_kernel, dim3(groups), dim3(256), 0, stream_, partials_.as<G1Xyzz>(), blocks_per_group,
+    hipLaunchKernelGGL(msm_group_partial_kernel, dim3(blocks_per_group, groups, m), dim3(256), 0, stream_, t_seg, w_seg,
+                       segs_per_sum, n_bits, partials_.as<G1Xyzz>());
+    hipLaunchKernelGGL(msm_group_final_kernel, dim3(groups * m), dim3(256), 0, stream_, partials_.as<G1Xyzz>(), blocks_per_group,
                        group_sums_.as<G1Proj>());
     ZK_HIP(hipGetLastError());
     n_groups = groups;
     log_seg_out = log_seg;
 }
 
-G1Proj MsmEngine::finish(uint32_t groups, uint32_t log_seg) {
-    std::vector<G1Proj> gs(groups);
-    ZK_HIP(hipMemcpyAsync(gs.data(), group_sums_.p, (size_t)groups * sizeof(G1Proj), hipMemcpyDeviceToHost, stream_));
+void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_t &n_groups, uint32_t &log_seg_out) {
+    msm_batch_device(1, &scalars_dev, &n, base, n_groups, log_seg_out);
+}
+
+void MsmEngine::finish_batch(uint32_t m, uint32_t groups, uint32_t log_seg, G1Proj *out) {
+    std::vector<G1Proj> all((size_t)m * groups);
+    ZK_HIP(hipMemcpyAsync(all.data(), group_sums_.p, all.size() * sizeof(G1Proj), hipMemcpyDeviceToHost, stream_));
     ZK_HIP(hipStreamSynchronize(stream_));
-    // sum_b (b+1) bucket_b = sum_s W_s + L * sum_k 2^k Q_k + sum_s T_s (group layout: msm_group_partial_kernel)
-    if (groups == 2) return g1_add(gs[0], gs[1]);
-    const uint32_t n_bits = groups - 3;
-    G1Proj total = G1Proj::identity();
-    for (int k = (int)n_bits - 1; k >= 0; k--) {
-        total = g1_double(total);
-        total = g1_add(total, gs[k]);
+    for (uint32_t j = 0; j < m; j++) {
+        const G1Proj *gs = all.data() + (size_t)j * groups;
+        // sum_b (b+1) bucket_b = sum_s W_s + L * sum_k 2^k Q_k + sum_s T_s (group layout: msm_group_partial_kernel)
+        if (groups == 2) {
+            out[j] = g1_add(gs[0], gs[1]);
+            continue;
+        }
+        const uint32_t n_bits = groups - 3;
+        G1Proj total = G1Proj::identity();
+        for (int k = (int)n_bits - 1; k >= 0; k--) {
+            total = g1_double(total);
+            total = g1_add(total, gs[k]);
+        }
+        for (uint32_t k = 0; k < log_seg; k++) total = g1_double(total);
+        total = g1_add(total, g1_add(gs[n_bits - 1], gs[n_bits]));
+        total = g1_add(total, g1_add(gs[n_bits + 1], gs[n_bits + 2]));
+        out[j] = total;
     }
-    for (uint32_t k = 0; k < log_seg; k++) total = g1_double(total);
-    total = g1_add(total, g1_add(gs[n_bits - 1], gs[n_bits]));
-    total = g1_add(total, g1_add(gs[n_bits + 1], gs[n_bits + 2]));
-    return total;
+}
+
+G1Proj MsmEngine::finish(uint32_t groups, uint32_t log_seg) {
+    G1Proj r;
+    finish_batch(1, groups, log_seg, &r);
+    return r;
 }
 
 G1Proj MsmEngine::msm(const Fr *scalars_dev, size_t n, size_t base) {
     uint32_t groups, log_seg;
     msm_device(scalars_dev, n, base, groups, log_seg);
     return finish(groups, log_seg);
+}
+
+void MsmEngine::msm_batch(uint32_t m, const Fr *const *scalars_dev, const size_t *lens, size_t base, G1Proj *out) {
+    uint32_t groups, log_seg;
+    msm_batch_device(m, scalars_dev, lens, base, groups, log_seg);
+    finish_batch(m, groups, log_seg, out);
 }
 
 }  // namespace zk

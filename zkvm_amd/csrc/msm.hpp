@@ -30,6 +30,14 @@ class MsmEngine {
     void msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_t &n_groups, uint32_t &log_seg);
     G1Proj finish(uint32_t n_groups, uint32_t log_seg);
 
+    // Up to MAX_BATCH sums over the same points in one pass: out[j] = sum_i scalars[j][i] * points[base + i],
+    // i < lens[j].  The sums share the accumulation launch and the latency-bound reduction launches.
+    static const uint32_t MAX_BATCH = 4;
+    void msm_batch(uint32_t m, const Fr *const *scalars_dev, const size_t *lens, size_t base, G1Proj *out);
+    void msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const size_t *lens, size_t base, uint32_t &n_groups,
+                          uint32_t &log_seg);
+    void finish_batch(uint32_t m, uint32_t n_groups, uint32_t log_seg, G1Proj *out);
+
     static uint32_t choose_window(size_t n);
     size_t device_bytes() const;
     // Test hooks: window width used by the next load_points*, segment width of the bucket reduction.

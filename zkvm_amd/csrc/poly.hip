@@ -454,17 +454,24 @@ __global__ void __launch_bounds__(1024) degree_kernel(const Fr *coeffs, uint64_t
         if (mine > *reinterpret_cast<volatile unsigned long long *>(out)) atomicMax(out, mine);
     }
 }
-uint64_t PolyEngine::length_without_leading_zeros(const Fr *coeffs, uint64_t len) {
-    if (len == 0) return 0;
+void PolyEngine::lengths_without_leading_zeros(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, uint64_t *out) {
+    ZK_REQUIRE(m <= 8, ZKGPU_ERR_INVALID_ARG, "lengths_without_leading_zeros: at most 8 vectors");
     jobs_.reserve(64);
     unsigned long long *d = jobs_.as<unsigned long long>();
-    ZK_HIP(hipMemsetAsync(d, 0, 8, stream_));
-    hipLaunchKernelGGL(degree_kernel, dim3(ceil_div(len, 4096)), dim3(1024), 0, stream_, coeffs, len, d);
+    ZK_HIP(hipMemsetAsync(d, 0, 8 * m, stream_));
+    for (uint32_t j = 0; j < m; j++)
+        if (lens[j])
+            hipLaunchKernelGGL(degree_kernel, dim3(ceil_div(lens[j], 4096)), dim3(1024), 0, stream_, coeffs[j], lens[j], d + j);
     ZK_HIP(hipGetLastError());
-    unsigned long long h = 0;
-    ZK_HIP(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream_));
+    unsigned long long h[8];
+    ZK_HIP(hipMemcpyAsync(h, d, 8 * m, hipMemcpyDeviceToHost, stream_));
     ZK_HIP(hipStreamSynchronize(stream_));
-    return (uint64_t)h;
+    for (uint32_t j = 0; j < m; j++) out[j] = (uint64_t)h[j];
+}
+uint64_t PolyEngine::length_without_leading_zeros(const Fr *coeffs, uint64_t len) {
+    uint64_t out = 0;
+    lengths_without_leading_zeros(1, &coeffs, &len, &out);
+    return out;
 }
 
 PolyEngine::~PolyEngine() {

@@ -65,6 +65,8 @@ class PolyEngine {
     // number of coefficients once leading zeros are dropped (Polynomial::truncate_leading_zeros,
     // plonk/src/fft/polynomial.rs:95-103); synchronises the stream
     uint64_t length_without_leading_zeros(const Fr *coeffs, uint64_t len);
+    // the same for up to 8 vectors with a single synchronisation
+    void lengths_without_leading_zeros(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, uint64_t *out);
 
     size_t device_bytes() const { return s0_.cap + s1_.cap + s2_.cap + s3_.cap + jobs_.cap; }
 

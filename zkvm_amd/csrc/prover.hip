@@ -95,6 +95,24 @@ int Prover::commit_dev(const Fr *coeffs, uint64_t len, AffineOut &out) {
     return 0;
 }
 
+// Several commitments over the same SRS in one batched MSM.  The reference commits one polynomial after the other
+// and returns the first error (prover.rs:262-265, 344-347): the degree checks run in that order before any work.
+int Prover::commit_many(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, AffineOut *out) {
+    uint64_t eff[MsmEngine::MAX_BATCH];
+    size_t eff_sz[MsmEngine::MAX_BATCH];
+    poly_.lengths_without_leading_zeros(m, coeffs, lens, eff);
+    for (uint32_t j = 0; j < m; j++) {
+        const uint64_t degree = eff[j] ? eff[j] - 1 : 0;
+        if (degree == 0) return ZKGPU_ERR_DEGREE_ZERO;
+        if (degree > msm_.n_points() - 1) return ZKGPU_ERR_DEGREE_LARGE;
+        eff_sz[j] = (size_t)eff[j];
+    }
+    G1Proj sums[MsmEngine::MAX_BATCH];
+    msm_.msm_batch(m, coeffs, eff_sz, 0, sums);
+    for (uint32_t j = 0; j < m; j++) out[j] = to_affine(sums[j]);
+    return 0;
+}
+
 void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector_evals_host, const std::string &label,
                       const uint64_t *pi_indexes, size_t n_pi) {
     ZK_REQUIRE(n >= 1 && (n & (n - 1)) == 0, ZKGPU_ERR_INVALID_ARG, "prover_key_load: n must be a power of two");
@@ -310,8 +328,11 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     Fr *wp[4] = {p_a, p_b, p_c, p_d};
     for (int k = 0; k < 4; k++) blind_poly(wires + k * n, 1, bl + 2 * k, wp[k]);
     int rc;
-    for (int k = 0; k < 4; k++)
-        if ((rc = commit_dev(wp[k], n + 2, out.comms[k]))) return rc;
+    {
+        const Fr *cp[4] = {p_a, p_b, p_c, p_d};
+        const uint64_t cl[4] = {n + 2, n + 2, n + 2, n + 2};
+        if ((rc = commit_many(4, cp, cl, &out.comms[0]))) return rc;
+    }
     tr.append_commitment("a_comm", out.comms[0]);
     tr.append_commitment("b_comm", out.comms[1]);
     tr.append_commitment("c_comm", out.comms[2]);
@@ -373,10 +394,11 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
         bool s4[1] = {true};
         poly_.patch(t_fourth, i4, &b14, s4, 1);  // t_fourth[0] -= b_14
     }
-    if ((rc = commit_dev(t_low, n + 1, out.comms[5]))) return rc;
-    if ((rc = commit_dev(t_mid, n + 1, out.comms[6]))) return rc;
-    if ((rc = commit_dev(t_high, n + 1, out.comms[7]))) return rc;
-    if ((rc = commit_dev(t_fourth, t4_len, out.comms[8]))) return rc;
+    {
+        const Fr *cp[4] = {t_low, t_mid, t_high, t_fourth};
+        const uint64_t cl[4] = {n + 1, n + 1, n + 1, t4_len};
+        if ((rc = commit_many(4, cp, cl, &out.comms[5]))) return rc;
+    }
     tr.append_commitment("t_low_comm", out.comms[5]);
     tr.append_commitment("t_mid_comm", out.comms[6]);
     tr.append_commitment("t_high_comm", out.comms[7]);
@@ -497,6 +519,10 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
         poly_.linear_combination(L);
     }
     lap(5, t_phase);
+    // Both opening witnesses are built first and committed together: the prover's transcript does not absorb
+    // w_z_chall_comm (prover.rs:439-479), so v_w does not depend on it.  t[0..3n) is free again and holds the second.
+    uint64_t wit_len = 0;
+    Fr *wit2 = t;
     {
         // compute_aggregate_witness (kzg10/key.rs:131-146) at z with powers of v
         LinArgs L;
@@ -517,7 +543,7 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
         L.out_len = len;
         poly_.linear_combination(L);
         poly_.ruffini(agg, len, z_ch, wit);
-        if ((rc = commit_dev(wit, len - 1, out.comms[9]))) return rc;
+        wit_len = len - 1;
     }
     const Fr v_w_ch = tr.challenge_scalar("v_w_challenge");
     {
@@ -536,8 +562,12 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
         L.out = agg;
         L.out_len = n + 3;
         poly_.linear_combination(L);
-        poly_.ruffini(agg, n + 3, z_w, wit);
-        if ((rc = commit_dev(wit, n + 2, out.comms[10]))) return rc;
+        poly_.ruffini(agg, n + 3, z_w, wit2);
+    }
+    {
+        const Fr *cp[2] = {wit, wit2};
+        const uint64_t cl[2] = {wit_len, n + 2};
+        if ((rc = commit_many(2, cp, cl, &out.comms[9]))) return rc;
     }
     lap(6, t_phase);
     const Fr chs[10] = {beta, gamma, alpha, range_ch, logic_ch, fixed_ch, var_ch, z_ch, v_ch, v_w_ch};

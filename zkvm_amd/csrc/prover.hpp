@@ -61,6 +61,7 @@ class Prover {
    private:
     // CommitKey::commit (kzg10/key.rs:108-129) of a device polynomial
     int commit_dev(const Fr *coeffs, uint64_t len, AffineOut &out);
+    int commit_many(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, AffineOut *out);
     void blind_poly(const Fr *evals_dev, int hiding_degree, const Fr *blinders, Fr *out_dev);
 
     hipStream_t stream_;

@@ -33,6 +33,22 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FR_TOP = np.uint64(0x73eda753299d7d48)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+# Integer-VALU ceilings measured on MI355X with tools/ubench.hip (whole chip, dependent chains, >= 2 waves per SIMD):
+FR_MUL_PEAK_G = 127.0    # G Fr Montgomery products / s
+FQ28_MUL_PEAK_G = 76.0   # G Fq products / s in the MSM's 28-bit-limb form
+
+
+def pmc_traffic(profile_csv, kernel):
+    """HBM bytes per launch of `kernel` from a committed hardware-counter summary (tools/pmc_summary.py output:
+    FETCH_SIZE doubled for gfx950, WRITE_SIZE as counted), or None when the file or the kernel is missing."""
+    import csv
+    path = os.path.join(ROOT, "profiles", profile_csv)
+    if not os.path.exists(path):
+        return None
+    for row in csv.DictReader(open(path)):
+        if row["kernel"].endswith(kernel):
+            return int(row["hbm_read_bytes_corrected"]) + int(row["hbm_write_bytes"])
+    return None
 
 
 def random_fr(n, seed):
@@ -132,12 +148,18 @@ def run_ntt(args, rank, world, local, device):
         launch_ms = ms / (reps * passes)
         alg_bytes_per_launch = 2 * (8 * n) * 32 / passes
         achieved = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        fr_products = (8 * n // 2) * (LOG_N + 3) / passes          # butterflies per launch, one Fr product each
+        g_products = fr_products / (launch_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "ntt_pass_kernel (2^23-point coset_fft, %d launches per transform)" % passes,
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(achieved / HBM_PEAK_GBS, 4),
+                           "traffic": pmc_traffic("r01_pmc_ntt.csv", "ntt_pass_kernel"),
+                           "traffic_note": "mean over the 2^20 and 2^23 launches of one bench step (profiles/r01_pmc_ntt.csv)",
                            "avg_launch_ms": round(launch_ms, 4),
                            "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
-                           "note": "VALU-bound (one Fr product per butterfly, ~300 VALU instructions each)"}
+                           "valu": {"unit": "G Fr products/s", "achieved": round(g_products, 1), "peak": FR_MUL_PEAK_G,
+                                    "frac": round(g_products / FR_MUL_PEAK_G, 3)},
+                           "note": "integer-VALU-bound: one Fr product plus an add and a subtract per butterfly"}
         out["per_transform_ms"] = {}
         for mode, lg, name in ((0, LOG_N, "fft_2^20"), (1, LOG_N, "ifft_2^20"), (2, LOG_N + 3, "coset_fft_2^23"),
                                (3, LOG_N + 3, "coset_ifft_2^23")):
@@ -190,7 +212,7 @@ def run_msm(args, rank, world, local, device):
     import zkvm_amd
     ctx = zkvm_amd.Context(local)
     from zkvm_amd import sharding
-    n_total = 1 << MSM_LOG
+    n_total = 1 << args.log_points
     base, shard = sharding.shard_range(n_total, rank, world)
     pts = synthetic_points(ctx, n_total, device)
     ctx.srs_load(pts[base:base + shard].contiguous())
@@ -218,6 +240,20 @@ def run_msm(args, rank, world, local, device):
         ms = ctx.timer_stop() / reps
         out["msm_device_phase_ms"] = round(ms, 3)
         out["result_x0"] = hex(int(res[0][0]))
+        phases = [ctx.msm_profile(scalars) for _ in range(reps)]
+        acc_ms = sum(p["accumulate"] for p in phases) / reps
+        out["msm_phase_ms"] = {k: round(sum(p[k] for p in phases) / reps, 3) for k in phases[0]}
+        windows = ctx.msm_get_params()[1]
+        alg = 128.0 * shard
+        achieved = alg / (acc_ms * 1e-3) / 1e9
+        products = 10.0 * shard * windows / (acc_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "msm_accumulate_kernel (this rank's %d points)" % shard,
+                           "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "avg_launch_ms": round(acc_ms, 4), "algorithmic_bytes_per_launch": int(alg),
+                           "valu": {"unit": "G Fq products/s", "achieved": round(products, 1), "peak": FQ28_MUL_PEAK_G,
+                                    "frac": round(products / FQ28_MUL_PEAK_G, 3)},
+                           "note": "integer-VALU-bound: %d table points per scalar, 10 Fq products each" % windows}
     value = args.steps * n_total / elapsed / 1e6
     return value, elapsed, out, ctx
 
@@ -285,8 +321,8 @@ def run_prove(args, rank, world, local, device):
         out["phase_ms"] = {k: round(v, 3) for k, v in timed["timings_ms"].items()}
         out["setup_s"] = {"circuit_host": round(t_circ, 2), "key_preprocess_gpu": round(t_key, 3)}
         out["proof_digest"] = {"a_comm_x0": hex(int(proof["comms"][0][0])), "z_eval_0": hex(int(proof["evals"][14][0]))}
-        # dominant kernel: msm_accumulate_kernel of the 11 commitments; time the MSM device phase of one
-        # n-point commitment with HIP events on the library's stream
+        # dominant kernel: msm_accumulate_kernel of the 11 commitments; HIP events on the library's stream around the
+        # phases of one n-point commitment
         sc = to_dev(random_fr(n, 3), device)
         reps = 5
         ctx.msm_kernels(sc)
@@ -295,8 +331,11 @@ def run_prove(args, rank, world, local, device):
         for _ in range(reps):
             ctx.msm_kernels(sc)
         msm_ms = ctx.timer_stop() / reps
+        phases = [ctx.msm_profile(sc) for _ in range(reps)]
         out["msm_2^%d_device_ms" % log_n] = round(msm_ms, 3)
-        out["_msm_ms"] = msm_ms
+        out["msm_2^%d_phase_ms" % log_n] = {k: round(sum(p[k] for p in phases) / reps, 3) for k in phases[0]}
+        out["_acc_ms"] = sum(p["accumulate"] for p in phases) / reps
+        out["_windows"] = ctx.msm_get_params()[1]
     value = world * args.steps / elapsed
     return value, elapsed, out, ctx
 
@@ -329,6 +368,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="prove", choices=["prove", "ntt", "msm"])
     ap.add_argument("--log-gates", type=int, default=PROVE_LOG)
+    ap.add_argument("--log-points", type=int, default=MSM_LOG)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -345,16 +385,23 @@ def main():
                                        "coset, linearization, openings), bit-exact vs the CPU prover" % args.log_gates,
                            "n": 1 << args.log_gates, "parallelism": "independent proofs per GPU"}}
         if rank == 0:
-            msm_ms = extra.pop("_msm_ms")
+            acc_ms = extra.pop("_acc_ms")
+            windows = extra.pop("_windows")
             n = 1 << args.log_gates
-            alg = 128.0 * n
-            achieved = alg / (msm_ms * 1e-3) / 1e9
-            extra["roofline"] = {"bound": "hbm", "kernel": "MSM device phase of one 2^%d-point commitment (msm_accumulate_kernel "
-                                                           "dominates)" % args.log_gates,
+            alg = 128.0 * n            # every point (96 B) and scalar (32 B) once
+            achieved = alg / (acc_ms * 1e-3) / 1e9
+            products = 10.0 * n * windows / (acc_ms * 1e-3) / 1e9    # 8 products + 2 squarings per mixed addition
+            extra["roofline"] = {"bound": "hbm", "kernel": "msm_accumulate_kernel of one 2^%d-point commitment (11 per proof)"
+                                                           % args.log_gates,
                                  "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                                 "algorithmic_bytes_per_launch": int(alg),
-                                 "note": "integer-VALU-bound: ~11 Fq products of ~620 VALU instructions per point and window"}
+                                 "frac": round(achieved / HBM_PEAK_GBS, 5),
+                                 "traffic": pmc_traffic("r01_pmc_msm20.csv", "msm_accumulate_kernel") if args.log_gates == 20 else None,
+                                 "traffic_note": "profiles/r01_pmc_msm20.csv: the same kernel on one 2^20-point commitment",
+                                 "avg_launch_ms": round(acc_ms, 4), "algorithmic_bytes_per_launch": int(alg),
+                                 "valu": {"unit": "G Fq products/s", "achieved": round(products, 1), "peak": FQ28_MUL_PEAK_G,
+                                          "frac": round(products / FQ28_MUL_PEAK_G, 3)},
+                                 "note": "integer-VALU-bound: %d table points per scalar, 10 Fq products each; the HBM fraction "
+                                         "only says that memory is not the limit" % windows}
     elif args.workload == "ntt":
         value, elapsed, extra, ctx = run_ntt(args, rank, world, local, device)
         line = {"metric": "Fr NTT GB/s", "unit": "GB/s", "scaling": "weak", "dtype": "u32x8 (255-bit Fr, Montgomery)",
@@ -365,7 +412,8 @@ def main():
         value, elapsed, extra, ctx = run_msm(args, rank, world, local, device)
         line = {"metric": "BLS12-381 G1 MSM Mpts/s", "unit": "Mpts/s", "scaling": "strong",
                 "dtype": "u32x12 (381-bit Fq, Montgomery)",
-                "config": {"workload": "KZG10 commit: 2^%d-point G1 MSM, uniform scalars" % MSM_LOG, "n": 1 << MSM_LOG,
+                "config": {"workload": "KZG10 commit: 2^%d-point G1 MSM, uniform scalars" % args.log_points,
+                           "n": 1 << args.log_points,
                            "parallelism": "point-range shards, 144-byte partial sums all-gathered over RCCL"}}
     if rank == 0:
         line.update({"value": round(value, 3), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -102,6 +102,9 @@ int zkgpu_srs_load_dev(zkgpu_ctx *ctx, const void *xy_dev, size_t n_points);
  * (1..6, 0 = default).  Results do not depend on them. */
 int zkgpu_msm_set_params(zkgpu_ctx *ctx, uint32_t window_bits, uint32_t segment_bits);
 
+/* Window width and number of table levels (signed digits per scalar) chosen for the loaded SRS. */
+int zkgpu_msm_get_params(zkgpu_ctx *ctx, uint32_t *window_bits, uint32_t *n_windows);
+
 /* msm_variable_base(&powers_of_g, scalars) followed by Commitment::from(G1Projective)
  * (coset-bls12_381/src/coset/multiscalar_mul.rs:143-220, kzg10/commitment.rs:34-38): the affine sum of
  * scalars[i] * powers_of_g[i] over i < min(n, n_points), as the reference's zip truncates.  `scalars` is a HOST
@@ -118,6 +121,10 @@ int zkgpu_msm_partial_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, siz
 int zkgpu_g1_sum_to_affine(const uint64_t *xyz, size_t count, uint64_t out_xy[12], uint8_t *out_infinity);
 /* Device phase of the MSM only (no host tail, no result): used to time the kernels. */
 int zkgpu_msm_kernels_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n);
+
+/* As zkgpu_msm_kernels_dev with HIP events on the context's stream at the phase boundaries: phase_ms = digits +
+ * sort + schedule, msm_accumulate_kernel alone, oversized buckets, bucket reduction (milliseconds). */
+int zkgpu_msm_profile_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, float phase_ms[4]);
 
 /* CommitKey::commit (kzg10/key.rs:108-129): degree check, then the MSM.  `coeffs` is a host buffer of `len`
  * coefficients as held by the reference's Polynomial (leading zeros allowed; the degree is computed as

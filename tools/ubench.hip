@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 #include "ff.cuh"
+#include "fq28.cuh"
 
 using namespace zk;
 
@@ -156,6 +157,7 @@ int main() {
     for (int tpb : {256, 512, 1024}) {
         if (run_field<Fr>("Fr::mul", tpb, 2048)) return 1;
         if (run_field<Fq>("Fq::mul", tpb, 2048)) return 1;
+        if (run_field<Fq28>("Fq28::mul", tpb, 2048)) return 1;
     }
     return 0;
 }

@@ -148,6 +148,18 @@ class Context:
     def msm_kernels(self, scalars_dev):
         self._check(self._lib.zkgpu_msm_kernels_dev(self._h, scalars_dev.data_ptr(), scalars_dev.numel() // 4))
 
+    def msm_get_params(self):
+        """-> (window bits, table levels = digits per scalar) of the loaded SRS."""
+        c, k = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._lib.zkgpu_msm_get_params(self._h, C.byref(c), C.byref(k)))
+        return int(c.value), int(k.value)
+
+    def msm_profile(self, scalars_dev):
+        """Phase times of one device MSM (HIP events on the library's stream), milliseconds."""
+        ms = (C.c_float * 4)()
+        self._check(self._lib.zkgpu_msm_profile_dev(self._h, scalars_dev.data_ptr(), scalars_dev.numel() // 4, ms))
+        return dict(zip(("sort", "accumulate", "oversized", "reduce"), [float(x) for x in ms]))
+
     def commit(self, coeffs):
         c = _np_u64(coeffs, 4)
         out = np.zeros(12, dtype=np.uint64)

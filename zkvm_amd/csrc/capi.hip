@@ -221,6 +221,15 @@ int zkgpu_msm_set_params(zkgpu_ctx *ctx, uint32_t window_bits, uint32_t segment_
     });
 }
 
+int zkgpu_msm_get_params(zkgpu_ctx *ctx, uint32_t *window_bits, uint32_t *n_windows) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(window_bits && n_windows, ZKGPU_ERR_INVALID_ARG, "msm_get_params: null output");
+        ZK_REQUIRE(ctx->msm->n_points() > 0, ZKGPU_ERR_NOT_LOADED, "no SRS loaded");
+        *window_bits = ctx->msm->window_bits();
+        *n_windows = ctx->msm->n_windows();
+    });
+}
+
 int zkgpu_msm(zkgpu_ctx *ctx, const uint64_t *scalars, size_t n, uint64_t out_xy[12], uint8_t *out_infinity) {
     return guarded(ctx, [&] {
         ZK_REQUIRE(scalars != nullptr || n == 0, ZKGPU_ERR_INVALID_ARG, "msm: null scalars");
@@ -249,6 +258,27 @@ int zkgpu_msm_kernels_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n) {
         ZK_REQUIRE(scalars_dev != nullptr && n > 0, ZKGPU_ERR_INVALID_ARG, "msm: null scalars");
         uint32_t K, c;
         ctx->msm->msm_device(static_cast<const Fr *>(scalars_dev), n, 0, K, c);
+    });
+}
+
+int zkgpu_msm_profile_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, float phase_ms[4]) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(scalars_dev != nullptr && n > 0 && phase_ms, ZKGPU_ERR_INVALID_ARG, "msm_profile: null argument");
+        hipEvent_t ev[5];
+        for (auto &e : ev) ZK_HIP(hipEventCreate(&e));
+        ctx->msm->set_profile_events(ev);
+        uint32_t groups, log_seg;
+        try {
+            ctx->msm->msm_device(static_cast<const Fr *>(scalars_dev), n, 0, groups, log_seg);
+        } catch (...) {
+            ctx->msm->set_profile_events(nullptr);
+            for (auto &e : ev) (void)hipEventDestroy(e);
+            throw;
+        }
+        ctx->msm->set_profile_events(nullptr);
+        ZK_HIP(hipEventSynchronize(ev[4]));
+        for (int i = 0; i < 4; i++) ZK_HIP(hipEventElapsedTime(&phase_ms[i], ev[i], ev[i + 1]));
+        for (auto &e : ev) (void)hipEventDestroy(e);
     });
 }
 

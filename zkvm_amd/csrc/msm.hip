@@ -724,6 +724,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     ZK_HIP(hipMemsetAsync(task_count, 0, 4, stream_));
     ZK_HIP(hipMemsetAsync(class_cursor, 0, (N_CLASSES + 1) * 4, stream_));
 
+    if (profile_) ZK_HIP(hipEventRecord(profile_[0], stream_));
     // per sum: digits and the count pass of its own items into its own B counters
     SortGeom geom[MAX_BATCH];
     uint32_t *dig[MAX_BATCH];
@@ -769,13 +770,16 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(1), dim3(64), 0, stream_, class_cursor);
     hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(nb, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), nb,
                        class_shift, class_cursor, order);
+    if (profile_) ZK_HIP(hipEventRecord(profile_[1], stream_));
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, table, sorted_.as<uint32_t>(),
                        offsets_.as<uint32_t>(), counts_.as<uint32_t>(), order, class_cursor + N_CLASSES, buckets_.as<G1Xyzz>());
+    if (profile_) ZK_HIP(hipEventRecord(profile_[2], stream_));
     const uint32_t big_grid = max_tasks < 2048 ? max_tasks : 2048;
     hipLaunchKernelGGL(msm_big_partial_kernel, dim3(big_grid), dim3(256), 0, stream_, table, sorted_.as<uint32_t>(),
                        tasks_.as<MsmTask>(), task_count, max_tasks, partials_.as<G1Xyzz>());
     hipLaunchKernelGGL(msm_big_combine_kernel, dim3(big_grid), dim3(256), 0, stream_, tasks_.as<MsmTask>(), task_count,
                        max_tasks, partials_.as<G1Xyzz>(), buckets_.as<G1Xyzz>());
+    if (profile_) ZK_HIP(hipEventRecord(profile_[3], stream_));
     // reduction of all sums together (partials_ is free again: the oversized-bucket kernels above have consumed it in
     // stream order); the segments of sum j are [j * segs_per_sum, (j + 1) * segs_per_sum)
     hipLaunchKernelGGL(msm_segment_kernel, dim3(ceil_div(n_segments, 256)), dim3(256), 0, stream_, buckets_.as<G1Xyzz>(), log_seg,
@@ -784,6 +788,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
                        segs_per_sum, n_bits, partials_.as<G1Xyzz>());
     hipLaunchKernelGGL(msm_group_final_kernel, dim3(groups * m), dim3(256), 0, stream_, partials_.as<G1Xyzz>(), blocks_per_group,
                        group_sums_.as<G1Proj>());
+    if (profile_) ZK_HIP(hipEventRecord(profile_[4], stream_));
     ZK_HIP(hipGetLastError());
     n_groups = groups;
     log_seg_out = log_seg;

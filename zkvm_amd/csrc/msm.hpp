@@ -38,6 +38,9 @@ class MsmEngine {
                           uint32_t &log_seg);
     void finish_batch(uint32_t m, uint32_t n_groups, uint32_t log_seg, G1Proj *out);
 
+    // Five HIP events recorded on the stream at the phase boundaries of the next device phases: start, before and
+    // after msm_accumulate_kernel, before the reduction, end.  nullptr switches the recording off.
+    void set_profile_events(hipEvent_t *five) { profile_ = five; }
     static uint32_t choose_window(size_t n);
     size_t device_bytes() const;
     // Test hooks: window width used by the next load_points*, segment width of the bucket reduction.
@@ -57,6 +60,7 @@ class MsmEngine {
     DevBuf counts_, offsets_, cursor_, sorted_, buckets_, block_sums_, tasks_, partials_, misc_, seg_, group_sums_;
     DevBuf order_, digits_;
     uint32_t window_override_ = 0;
+    hipEvent_t *profile_ = nullptr;
     bool lds_attr_set_ = false;
 };
 

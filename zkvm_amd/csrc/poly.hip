@@ -428,6 +428,24 @@ void PolyEngine::patch(Fr *p, const uint64_t *idx, const Fr *vals, const bool *s
     ZK_HIP(hipGetLastError());
 }
 
+// ---- scatter -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) scatter_kernel(Fr *dst, const uint64_t *idx, const Fr *vals, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) st(dst + idx[i], ld(vals + i));
+}
+void PolyEngine::zero_and_scatter(Fr *dst, uint64_t len, const uint64_t *idx_host, const Fr *vals_host, uint32_t count) {
+    ZK_HIP(hipMemsetAsync(dst, 0, len * sizeof(Fr), stream_));
+    if (!count) return;
+    s3_.reserve((size_t)count * (sizeof(Fr) + 8));
+    Fr *vals = s3_.as<Fr>();
+    uint64_t *idx = reinterpret_cast<uint64_t *>(vals + count);
+    ZK_HIP(hipMemcpyAsync(vals, vals_host, (size_t)count * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+    ZK_HIP(hipMemcpyAsync(idx, idx_host, (size_t)count * 8, hipMemcpyHostToDevice, stream_));
+    hipLaunchKernelGGL(scatter_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, stream_, dst, idx, vals, count);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(stream_));   // the host arrays are the caller's temporaries
+}
+
 // ---- degree -------------------------------------------------------------------------------------------------
 // *out = 1 + index of the highest non-zero coefficient (0 for the zero polynomial)
 __global__ void __launch_bounds__(1024) degree_kernel(const Fr *coeffs, uint64_t len, unsigned long long *out) {

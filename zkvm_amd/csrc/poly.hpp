@@ -64,6 +64,8 @@ class PolyEngine {
 
     // number of coefficients once leading zeros are dropped (Polynomial::truncate_leading_zeros,
     // plonk/src/fft/polynomial.rs:95-103); synchronises the stream
+    // dst[0..len) = 0, then dst[idx[k]] = vals[k] for distinct indexes below len (host arrays)
+    void zero_and_scatter(Fr *dst, uint64_t len, const uint64_t *idx_host, const Fr *vals_host, uint32_t count);
     uint64_t length_without_leading_zeros(const Fr *coeffs, uint64_t len);
     // the same for up to 8 vectors with a single synchronisation
     void lengths_without_leading_zeros(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, uint64_t *out);

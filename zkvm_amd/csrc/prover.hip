@@ -1,5 +1,6 @@
 // Host orchestration of preprocess and prove over the device engines (see prover.hpp).
 #include "prover.hpp"
+#include <map>
 #include "widgets.cuh"
 #include <chrono>
 #include <cstring>
@@ -361,11 +362,18 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     const Fr var_ch = tr.challenge_scalar("variable base separation challenge");
     {
         // composer.rs:1001-1014 dense public inputs, then ifft (prover.rs:305-306)
-        std::vector<Fr> dense(n, Fr::zero());
+        // The dense vector is built on the device from the few (index, value) pairs; a later pair with the same index
+        // overrides an earlier one, as the reference's sequential writes do.
+        std::map<uint64_t, Fr> last;
         for (size_t i = 0; i < pi_indexes_.size() && i < n_pi; i++)
-            if (pi_indexes_[i] < n) dense[pi_indexes_[i]] = public_inputs[i];
-        ZK_HIP(hipMemcpyAsync(p_pi, dense.data(), n * sizeof(Fr), hipMemcpyHostToDevice, stream_));
-        ZK_HIP(hipStreamSynchronize(stream_));
+            if (pi_indexes_[i] < n) last[pi_indexes_[i]] = public_inputs[i];
+        std::vector<uint64_t> idx;
+        std::vector<Fr> vals;
+        for (auto &kv : last) {
+            idx.push_back(kv.first);
+            vals.push_back(kv.second);
+        }
+        poly_.zero_and_scatter(p_pi, n, idx.data(), vals.data(), (uint32_t)idx.size());
         ntt_.transform(NTT_IFFT, p_pi, n, p_pi, log_n_);
     }
     const Fr ch7[7] = {alpha, beta, gamma, range_ch, logic_ch, fixed_ch, var_ch};

@@ -206,6 +206,87 @@ __global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t *dig, Sor
     }
 }
 
+// ---- two-level variant for more than one bucket range ----------------------------------------------------------
+// With B > 2^15 buckets the one-level sort above makes every bucket range scan the whole digit list.  Here the
+// items are first partitioned by bucket range (a counting sort with n_ranges bins, items of one workgroup counted
+// and placed with LDS atomics), then every range sorts only its own items with the LDS histogram.
+static const uint32_t RANGE_ITEMS = 4096;   // items per workgroup in the range partition
+// pass 0: blockcnt[r * n_blocks + blk] = items of block blk in range r;  pass 1: place them
+//   mid_key = bucket index inside the range | sign << 31,  mid_val = table index w * stride + base + i
+template <int PASS>
+__global__ void __launch_bounds__(256) msm_range_kernel(const uint32_t *dig, SortGeom g, uint32_t n_ranges, uint32_t n_blocks,
+                                                        uint32_t *blockcnt, uint32_t *mid_key, uint32_t *mid_val) {
+    __shared__ uint32_t bins[128];
+    const uint32_t blk = blockIdx.x;
+    for (uint32_t t = threadIdx.x; t < n_ranges; t += 256) bins[t] = PASS ? blockcnt[(size_t)t * n_blocks + blk] : 0u;
+    __syncthreads();
+    const uint32_t lo = blk * RANGE_ITEMS;
+    uint32_t vv[RANGE_ITEMS / 256];
+#pragma unroll
+    for (uint32_t u = 0; u < RANGE_ITEMS / 256; u++) {
+        const uint32_t j = lo + u * 256 + threadIdx.x;
+        vv[u] = j < g.n_items ? dig[j] : 0u;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < RANGE_ITEMS / 256; u++) {
+        const uint32_t j = lo + u * 256 + threadIdx.x, v = vv[u];
+        const uint32_t mag = v & 0x7fffffffu;
+        if (!mag) continue;
+        const uint32_t b = mag - 1, r = b >> g.log_range;
+        const uint32_t pos = atomicAdd(&bins[r], 1u);
+        if (PASS) {
+            const uint32_t w = j / g.n, i = j - w * g.n;
+            mid_key[pos] = (b & ((1u << g.log_range) - 1u)) | (v & 0x80000000u);
+            mid_val[pos] = w * g.stride + g.base + i;
+        }
+    }
+    if (!PASS) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < n_ranges; t += 256) blockcnt[(size_t)t * n_blocks + blk] = bins[t];
+    }
+}
+// adds the scanned block sums: offsets[i] += block_sums[i / SCAN_ITEMS]
+__global__ void __launch_bounds__(256) scan_add_kernel(uint32_t *offsets, const uint32_t *block_sums, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) offsets[i] += block_sums[i / SCAN_ITEMS];
+}
+// Workgroup (s, r) owns slice s of range r's items [range_start[r * n_blocks], range_start[(r + 1) * n_blocks]).
+template <int PASS>
+__global__ void __launch_bounds__(1024) msm_sort2_kernel(const uint32_t *mid_key, const uint32_t *mid_val,
+                                                         const uint32_t *range_start, uint32_t n_blocks, SortGeom g,
+                                                         uint32_t *part, uint32_t *sorted) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t range = 1u << g.log_range;
+    const uint32_t s = blockIdx.x, r = blockIdx.y;
+    uint32_t *mine = part + (size_t)s * g.B + ((size_t)r << g.log_range);
+    for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) hist[t] = PASS ? mine[t] : 0u;
+    __syncthreads();
+    const uint32_t first = range_start[(size_t)r * n_blocks], last = range_start[(size_t)(r + 1) * n_blocks];
+    const uint32_t slice = (last - first + g.S - 1) / g.S;
+    const uint32_t lo = first + s * slice;
+    uint32_t hi = lo + slice;
+    if (hi > last) hi = last;
+    for (uint32_t j0 = lo + threadIdx.x; j0 < hi; j0 += 4 * blockDim.x) {
+        uint32_t kk[4], vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t j = j0 + u * blockDim.x;
+            kk[u] = j < hi ? mid_key[j] : 0xffffffffu;
+            if (PASS) vv[u] = j < hi ? mid_val[j] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (j0 + u * blockDim.x >= hi) continue;
+            const uint32_t pos = atomicAdd(&hist[kk[u] & 0x7fffffffu], 1u);
+            if (PASS) sorted[pos] = vv[u] | (kk[u] & 0x80000000u);
+        }
+    }
+    if (!PASS) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) mine[t] = hist[t];
+    }
+}
+
 // counts[b] = sum over slices
 __global__ void __launch_bounds__(256) msm_totals_kernel(const uint32_t *part, uint32_t B, uint32_t S, uint32_t *counts) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -577,13 +658,13 @@ __global__ void msm_mark_infinity_kernel(G1Affine *points, const uint8_t *inf, u
 // ---------------------------------------------------------------------------------------------------------
 MsmEngine::~MsmEngine() {
     DevBuf *all[] = {&points_, &counts_, &offsets_, &cursor_, &sorted_, &buckets_, &block_sums_, &tasks_, &partials_,
-                     &misc_,   &seg_,    &group_sums_, &order_, &digits_, &table28_};
+                     &misc_,   &seg_,    &group_sums_, &order_, &digits_, &table28_, &range_cnt_, &mid_};
     for (DevBuf *b : all) b->release();
 }
 
 size_t MsmEngine::device_bytes() const {
     return points_.cap + counts_.cap + offsets_.cap + cursor_.cap + sorted_.cap + buckets_.cap + block_sums_.cap +
-           tasks_.cap + partials_.cap + misc_.cap + seg_.cap + group_sums_.cap + order_.cap + digits_.cap + table28_.cap;
+           tasks_.cap + partials_.cap + misc_.cap + seg_.cap + group_sums_.cap + order_.cap + digits_.cap + table28_.cap + range_cnt_.cap + mid_.cap;
 }
 
 // Window width for a table of n points: minimises n * K * 11 products of accumulation plus ~30 products per
@@ -698,9 +779,20 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort_kernel<1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort2_kernel<0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort2_kernel<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         lds_attr_set_ = true;
     }
 
+    size_t range_cnt_stride = 0;
+    if (n_ranges > 1) {
+        const size_t n_cnt_max = (size_t)n_ranges * ceil_div(max_items, RANGE_ITEMS) + 1;
+        range_cnt_stride = n_cnt_max + ceil_div(n_cnt_max, SCAN_ITEMS) + 8;
+        range_cnt_.reserve((size_t)m * range_cnt_stride * 4);
+        mid_.reserve((size_t)m * 2 * max_items * 4);
+    }
     counts_.reserve((size_t)nb * 4);
     offsets_.reserve((size_t)nb * 4);
     cursor_.reserve((size_t)nb * S_max * 4);            // per-(sum, slice, bucket) counts, then cursors
@@ -746,8 +838,28 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
         uint32_t *part = cursor_.as<uint32_t>() + (size_t)j * B * S_max;
         hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(lens[j], 256)), dim3(256), 0, stream_, scalars_dev[j],
                            (uint32_t)lens[j], c, K, dig[j]);
-        hipLaunchKernelGGL(msm_sort_kernel<0>, dim3(S, n_ranges), dim3(1024), lds_bytes, stream_, dig[j], geom[j], part,
-                           sorted_.as<uint32_t>());
+        if (n_ranges == 1) {
+            hipLaunchKernelGGL(msm_sort_kernel<0>, dim3(S, n_ranges), dim3(1024), lds_bytes, stream_, dig[j], geom[j], part,
+                               sorted_.as<uint32_t>());
+        } else {
+            // range partition: count, scan (range-major, one extra entry = the total), place
+            const uint32_t n_blocks = ceil_div(n_items, RANGE_ITEMS), n_cnt = n_ranges * n_blocks + 1;
+            const uint32_t n_cnt_blocks = ceil_div(n_cnt, SCAN_ITEMS);
+            uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
+            uint32_t *range_sums = blockcnt + n_cnt;
+            uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
+            ZK_HIP(hipMemsetAsync(blockcnt + n_cnt - 1, 0, 4, stream_));
+            hipLaunchKernelGGL(msm_range_kernel<0>, dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
+                               blockcnt, mkey, mval);
+            hipLaunchKernelGGL(scan_block_kernel, dim3(n_cnt_blocks), dim3(256), 0, stream_, blockcnt, blockcnt, range_sums, n_cnt);
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream_, range_sums, n_cnt_blocks);
+            hipLaunchKernelGGL(scan_add_kernel, dim3(ceil_div(n_cnt, 256)), dim3(256), 0, stream_, blockcnt, range_sums, n_cnt);
+            hipLaunchKernelGGL(msm_range_kernel<1>, dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
+                               blockcnt, mkey, mval);
+            // msm_range_kernel<1> advanced nothing in global memory: blockcnt still holds the start positions
+            hipLaunchKernelGGL(msm_sort2_kernel<0>, dim3(S, n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt, n_blocks,
+                               geom[j], part, sorted_.as<uint32_t>());
+        }
         hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, part, B, S,
                            counts_.as<uint32_t>() + (size_t)j * B);
     }
@@ -761,8 +873,16 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
         uint32_t *part = cursor_.as<uint32_t>() + (size_t)j * B * S_max;
         hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, part,
                            offsets_.as<uint32_t>() + (size_t)j * B, B, geom[j].S);
-        hipLaunchKernelGGL(msm_sort_kernel<1>, dim3(geom[j].S, n_ranges), dim3(1024), lds_bytes, stream_, dig[j], geom[j], part,
-                           sorted_.as<uint32_t>());
+        if (n_ranges == 1) {
+            hipLaunchKernelGGL(msm_sort_kernel<1>, dim3(geom[j].S, n_ranges), dim3(1024), lds_bytes, stream_, dig[j], geom[j], part,
+                               sorted_.as<uint32_t>());
+        } else {
+            const uint32_t n_blocks = ceil_div(geom[j].n_items, RANGE_ITEMS);
+            const uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
+            const uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
+            hipLaunchKernelGGL(msm_sort2_kernel<1>, dim3(geom[j].S, n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt,
+                               n_blocks, geom[j], part, sorted_.as<uint32_t>());
+        }
     }
     // schedule: class histogram, scan, placement
     hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(nb, 1024)), dim3(1024), 0, stream_, counts_.as<uint32_t>(), nb,

@@ -56,8 +56,12 @@ extern "C" {
     pub fn zkgpu_ntt_dev(ctx: *mut zkgpu_ctx, in_dev: *const c_void, len_in: usize, out_dev: *mut c_void, log_n: u32,
                          mode: c_int) -> c_int;
 
+    pub fn zkgpu_ntt_set_params(ctx: *mut zkgpu_ctx, tile_log: u32, elems_per_thread_log: u32) -> c_int;
+
     pub fn zkgpu_srs_load(ctx: *mut zkgpu_ctx, xy: *const u64, infinity: *const u8, n_points: usize) -> c_int;
     pub fn zkgpu_srs_load_dev(ctx: *mut zkgpu_ctx, xy_dev: *const c_void, n_points: usize) -> c_int;
+    pub fn zkgpu_msm_set_params(ctx: *mut zkgpu_ctx, window_bits: u32, segment_bits: u32) -> c_int;
+    pub fn zkgpu_msm_get_params(ctx: *mut zkgpu_ctx, window_bits: *mut u32, n_windows: *mut u32) -> c_int;
     pub fn zkgpu_msm(ctx: *mut zkgpu_ctx, scalars: *const u64, n: usize, out_xy: *mut u64, out_infinity: *mut u8) -> c_int;
     pub fn zkgpu_msm_dev(ctx: *mut zkgpu_ctx, scalars_dev: *const c_void, n: usize, out_xy: *mut u64,
                          out_infinity: *mut u8) -> c_int;
@@ -65,8 +69,14 @@ extern "C" {
                                  out_xyz: *mut u64) -> c_int;
     pub fn zkgpu_g1_sum_to_affine(xyz: *const u64, count: usize, out_xy: *mut u64, out_infinity: *mut u8) -> c_int;
     pub fn zkgpu_msm_kernels_dev(ctx: *mut zkgpu_ctx, scalars_dev: *const c_void, n: usize) -> c_int;
+    pub fn zkgpu_msm_profile_dev(ctx: *mut zkgpu_ctx, scalars_dev: *const c_void, n: usize, phase_ms: *mut f32) -> c_int;
     pub fn zkgpu_commit(ctx: *mut zkgpu_ctx, coeffs: *const u64, len: usize, out_xy: *mut u64, out_infinity: *mut u8)
                         -> c_int;
+    pub fn zkgpu_field_mul_selfcheck(field: c_int, a: *const u64, b: *const u64, count: usize, out: *mut u64) -> c_int;
+    pub fn zkgpu_g1_bucket_selfcheck(xy: *const u64, infinity: *const u8, negate: *const u8, n: usize, out_xyz: *mut u64,
+                                     violations: *mut u64) -> c_int;
+    pub fn zkgpu_g1_bucket_selfcheck_tree(xy: *const u64, infinity: *const u8, negate: *const u8, n: usize,
+                                          out_xyz: *mut u64, violations: *mut u64) -> c_int;
     pub fn zkgpu_g1_compress(xy: *const u64, infinity: u8, out: *mut u8) -> c_int;
 
     pub fn zkgpu_prover_key_load(ctx: *mut zkgpu_ctx, n: u32, constraints: u64, selector_evals: *const u64,

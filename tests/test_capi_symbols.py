@@ -63,3 +63,15 @@ def test_host_compress_and_sum(orc):
     assert sinf == 0 and zkvm_amd.g1_compress(sxy, sinf) == data[48 * 38:48 * 39]
     sxy, sinf = zkvm_amd.g1_sum_to_affine(np.zeros((0, 18), np.uint64))
     assert sinf == 1 and zkvm_amd.g1_compress(sxy, sinf) == data[:48]
+
+
+def test_rust_bindings_declare_every_entry_point():
+    """rust/zkgpu-sys mirrors include/zkgpu.h one to one (it cannot be compiled here, so at least keep it complete)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "zkgpu.h")).read()
+    rust = open(os.path.join(root, "rust", "zkgpu-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"\b(zkgpu_[a-z0-9_]+)\s*\(", header))
+    bound = set(re.findall(r"pub fn (zkgpu_[a-z0-9_]+)", rust))
+    assert declared == bound

@@ -165,15 +165,17 @@ struct Fp_ {
         if (s + P::UL > 32 && w + 1 < N) lo |= x.v[w + 1] << (32 - s);
         return lo & MASK;
     }
-    FF_HD static Fp_ mul(const Fp_ &a, const Fp_ &b) {
+    // x[i] = bits [UL i - shift, UL i - shift + UL) of a: the integer a * 2^shift in UN limbs of UL bits
+    FF_HD static void unpack(const Fp_ &a, uint32_t *x, int shift) {
+#pragma unroll
+        for (int i = 0; i < P::UN; i++) x[i] = unpack_limb(a, P::UL * i - shift);
+    }
+    // r = x * y / 2^(UL*UN) mod p on limbs: r normalised (limbs < 2^UL) and below x y / 2^(UL*UN) + p.
+    // Needs every column sum below 2^64: UN * (max x limb) * (max y limb) + UN * 2^(2 UL) < 2^64.
+    FF_HD static void mul_limbs(const uint32_t *x, const uint32_t *y, uint32_t *r) {
         constexpr int UL = P::UL, UN = P::UN;
         constexpr uint32_t MASK = (1u << UL) - 1u;
-        uint32_t x[UN], y[UN], m[UN], r[UN];
-#pragma unroll
-        for (int i = 0; i < UN; i++) {
-            x[i] = unpack_limb(a, UL * i);
-            y[i] = unpack_limb(b, UL * i - P::USH);
-        }
+        uint32_t m[UN];
         uint64_t c = 0;
 #pragma unroll
         for (int k = 0; k < UN; k++) {
@@ -195,7 +197,11 @@ struct Fp_ {
             c >>= UL;
         }
         r[UN - 1] = (uint32_t)c;
-        // r < 2p: subtract p once if r >= p
+    }
+    // normalised r < 2p -> r mod p
+    FF_HD static void cond_sub_limbs(uint32_t *r) {
+        constexpr int UL = P::UL, UN = P::UN;
+        constexpr uint32_t MASK = (1u << UL) - 1u;
         uint32_t d[UN], borrow = 0;
 #pragma unroll
         for (int i = 0; i < UN; i++) {
@@ -205,7 +211,10 @@ struct Fp_ {
         }
 #pragma unroll
         for (int i = 0; i < UN; i++) r[i] = borrow ? r[i] : d[i];
-        // back to 32-bit words
+    }
+    // normalised limbs of a value below 2^(32 N) -> 32-bit words
+    FF_HD static Fp_ pack(const uint32_t *r) {
+        constexpr int UL = P::UL, UN = P::UN;
         Fp_ o;
 #pragma unroll
         for (int w = 0; w < N; w++) {
@@ -216,6 +225,14 @@ struct Fp_ {
             o.v[w] = lo;
         }
         return o;
+    }
+    FF_HD static Fp_ mul(const Fp_ &a, const Fp_ &b) {
+        uint32_t x[P::UN], y[P::UN], r[P::UN];
+        unpack(a, x, 0);
+        unpack(b, y, P::USH);
+        mul_limbs(x, y, r);   // < 2p
+        cond_sub_limbs(r);
+        return pack(r);
     }
     FF_HD static Fp_ sqr(const Fp_ &a) { return mul(a, a); }
 

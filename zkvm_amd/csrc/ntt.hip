@@ -118,10 +118,59 @@ __device__ __forceinline__ Fr fr_div_pow2(const Fr &x, uint32_t k) {
     return r;
 }
 
+// ---- tile arithmetic on unsaturated limbs ----------------------------------------------------------------------
+// Inside a pass an element is 9 limbs of 29 bits, only loosely reduced; one LDS plane per limb (conflict-free 4-byte
+// accesses).  The stage tables hold 32 w (i.e. w 2^261 in Montgomery-256 terms), so that the limb product
+// d * (32 w) / 2^261 = d w / 2^256 keeps the data in the reference's Montgomery scaling, and because the table entry
+// is reduced the product contracts: below d / 2^6 + r.  The sum path doubles per stage instead, so values are pulled
+// back below 2r every fourth stage (on read) with one quotient estimate from the top limb:
+//   stage k of a pass: inputs below 2^(k mod 4) * 2r;  s = x + y;  d = (x - y + M r) * w with M = 2^(k mod 4) * 4.
+static const uint32_t U9_MASK = 0x1fffffffu;
+template <int KM>
+__device__ __forceinline__ void ntt_bias(uint32_t *b) {   // M r with M = 4 * 2^KM, limbs raised by 2^29 below the top
+    constexpr uint32_t T[4][9] = {
+        {0x20000004u, 0x3fffffdfu, 0x3e5bfefeu, 0x2d2017feu, 0x360154eeu, 0x30101342u, 0x3483339cu, 0x2994cebdu, 0x01cfb69cu},
+        {0x20000008u, 0x3fffffbfu, 0x3cb7fdfeu, 0x3a402ffeu, 0x2c02a9ddu, 0x20202686u, 0x2906673au, 0x33299d7cu, 0x039f6d39u},
+        {0x20000010u, 0x3fffff7fu, 0x396ffbfeu, 0x34805ffeu, 0x380553bcu, 0x20404d0du, 0x320cce75u, 0x26533af9u, 0x073eda74u},
+        {0x20000020u, 0x3ffffeffu, 0x32dff7feu, 0x2900bffeu, 0x300aa77au, 0x20809a1cu, 0x24199cebu, 0x2ca675f4u, 0x0e7db4e9u}};
+#pragma unroll
+    for (int i = 0; i < 9; i++) b[i] = T[KM][i];
+}
+__device__ __forceinline__ void u9_load(const uint32_t *lds, uint32_t E, uint32_t e, uint32_t *x) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) x[k] = lds[k * E + e];
+}
+__device__ __forceinline__ void u9_store(uint32_t *lds, uint32_t E, uint32_t e, const uint32_t *x) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) lds[k * E + e] = x[k];
+}
+__device__ __forceinline__ void u9_normalize(uint32_t *x) {   // carries into the top limb; value unchanged
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t t = x[k] + c;
+        x[k] = t & U9_MASK;
+        c = t >> 29;
+    }
+    x[8] += c;
+}
+// normalised x below 64r -> normalised, below r + 66 * 2^232 (so below 2r): subtracts q r with
+// q = floor(top limb / (floor(r / 2^232) + 1)) <= x / r
+__device__ __forceinline__ void u9_qreduce(uint32_t *x) {
+    const uint32_t q = x[8] / 7597480u;
+    int64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        c += (int64_t)x[k] - (int64_t)((uint64_t)q * FrParams::umod(k));
+        x[k] = (uint32_t)c & U9_MASK;
+        c >>= 29;
+    }
+    x[8] = (uint32_t)(c + (int64_t)x[8] - (int64_t)((uint64_t)q * FrParams::umod(8)));
+}
+
 __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPassArgs a) {
-    extern __shared__ uint4 lds[];
+    extern __shared__ uint32_t lds[];
     const uint32_t R = 1u << a.log_r, T = 1u << a.log_t, E = R * T;
-    uint4 *lo = lds, *hi = lds + E;
     const uint32_t tid = threadIdx.x, nt = blockDim.x, tile = blockIdx.x;
     const uint32_t pb = a.log_n - a.log_r - a.b0;  // prefix bits above the row field
 
@@ -157,47 +206,79 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPassArgs a) {
                 x = x * g;
             }
         }
-        lds_put(lo, hi, j * T + t, x);
+        uint32_t u[9];
+        Fr::unpack(x, u, 0);
+        u9_store(lds, E, j * T + t, u);
     }
 
     // ---- butterflies ----
-    for (uint32_t hj = R >> 1; hj >= 1; hj >>= 1) {
+    uint32_t stage = 0;
+    for (uint32_t hj = R >> 1; hj >= 1; hj >>= 1, stage++) {
         __syncthreads();
         const uint32_t h = hj << a.b0;  // half-size of this stage in the whole network
         const uint32_t lhj = 31 - __clz(hj);
+        const uint32_t km = stage & 3u;
+        const bool reduce_in = km == 0 && stage > 0;
+        uint32_t bias[9];   // literals selected by uniform branches (a table indexed by km would be fetched from memory)
+        if (km == 0) ntt_bias<0>(bias);
+        else if (km == 1) ntt_bias<1>(bias);
+        else if (km == 2) ntt_bias<2>(bias);
+        else ntt_bias<3>(bias);
         for (uint32_t bi = tid; bi < (E >> 1); bi += nt) {
             const uint32_t t = bi & (T - 1);
             const uint32_t jb = bi >> a.log_t;
             const uint32_t off = jb & (hj - 1);
             const uint32_t j = ((jb >> lhj) << (lhj + 1)) | off;
             const uint32_t e0 = j * T + t, e1 = e0 + hj * T;
-            Fr x = lds_get(lo, hi, e0), y = lds_get(lo, hi, e1);
-            Fr s = x + y, d = x - y;
+            uint32_t x[9], y[9], d[9];
+            u9_load(lds, E, e0, x);
+            u9_load(lds, E, e1, y);
+            if (reduce_in) {
+                u9_qreduce(x);
+                u9_qreduce(y);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                d[k] = x[k] + (bias[k] - y[k]);
+                x[k] += y[k];
+            }
+            u9_normalize(x);
             if (h > 1 || !a.unit_last) {
                 const uint32_t widx = (off << a.b0) + (a.last ? 0u : col0 + t);
-                d = d * gload(a.tw + (h - 1) + widx);
+                uint32_t w[9];
+                Fr::unpack(gload(a.tw + (h - 1) + widx), w, 0);
+                Fr::mul_limbs(d, w, y);
+                u9_store(lds, E, e1, y);
+            } else {
+                u9_normalize(d);
+                u9_store(lds, E, e1, d);
             }
-            lds_put(lo, hi, e0, s);
-            lds_put(lo, hi, e1, d);
+            u9_store(lds, E, e0, x);
         }
     }
     __syncthreads();
 
-    // ---- store ----
+    // ---- store: back to the canonical 32-bit-word form ----
     for (uint32_t e = tid; e < E; e += nt) {
+        uint32_t le, gi;
         if (!a.last) {
             const uint32_t j = e >> a.log_t, t = e & (T - 1);
-            const uint32_t gi = base | (j << a.b0) | t;
-            gstore(a.out + gi, lds_get(lo, hi, e));
+            gi = base | (j << a.b0) | t;
+            le = e;
         } else {
             // consecutive lanes -> consecutive output positions: the column index is bit-reversed
             const uint32_t tr = e & (T - 1), j = e >> a.log_t;
             const uint32_t t = a.log_t ? (__brev(tr) >> (32 - a.log_t)) : 0u;
-            const uint32_t gi = ((((t << (pb - a.log_t)) | base)) << a.log_r) | j;
-            const uint32_t oi = a.log_n ? (__brev(gi) >> (32 - a.log_n)) : 0u;
-            Fr x = lds_get(lo, hi, j * T + t);
-            gstore(a.out + oi, fr_div_pow2(x, a.inv_shift));
+            const uint32_t src = ((((t << (pb - a.log_t)) | base)) << a.log_r) | j;
+            gi = a.log_n ? (__brev(src) >> (32 - a.log_n)) : 0u;
+            le = j * T + t;
         }
+        uint32_t u[9];
+        u9_load(lds, E, le, u);
+        u9_qreduce(u);
+        Fr::cond_sub_limbs(u);
+        Fr x = Fr::pack(u);
+        gstore(a.out + gi, a.last ? fr_div_pow2(x, a.inv_shift) : x);
     }
 }
 
@@ -231,6 +312,7 @@ __global__ void gen_powers_kernel(Fr *out, uint32_t count, Fr base) {
 // ---------------------------------------------------------------------------------------------------------
 NttEngine::~NttEngine() {
     tw_fwd_.release();
+    tw_plain_.release();
     tw_inv_.release();
     for (auto &kv : tw_cinv_) kv.second.release();
     gpow_lo_.release();
@@ -246,14 +328,16 @@ size_t NttEngine::device_bytes() const {
 }
 
 static void fill_stage_tables(hipStream_t stream, DevBuf &consts_buf, Fr *table, uint32_t log_n, const Fr &w_n,
-                              const Fr *coset_base /* g^-1 or null */) {
+                              const Fr *coset_base /* g^-1 or null */, bool times_32) {
     // stage q (half-size h = 2^q) uses w_{2h} = w_n^(n/2h) and, for the coset table, c_q = g^(-n/2h)
     std::vector<Fr> consts(2 * 32, Fr::one());
     Fr w = w_n;  // w_{2h} for q = log_n - 1
     Fr c = coset_base ? *coset_base : Fr::one();
+    // the transform's tables carry a factor 32 (see the tile arithmetic above); the plain table feeds roots_half()
+    const Fr scale = times_32 ? Fr::from_u32(32) : Fr::one();
     for (int q = (int)log_n - 1; q >= 0; q--) {
         consts[2 * q] = w;
-        consts[2 * q + 1] = coset_base ? c : Fr::one();
+        consts[2 * q + 1] = Fr::mul(coset_base ? c : Fr::one(), scale);
         w = Fr::sqr(w);
         if (coset_base) c = Fr::sqr(c);
     }
@@ -275,15 +359,21 @@ void NttEngine::ensure_tables(uint32_t log_n) {
     size_t bytes = ((1ull << log_n)) * sizeof(Fr);
     tw_fwd_.reserve(bytes);
     tw_inv_.reserve(bytes);
-    fill_stage_tables(stream_, stage_consts_, tw_fwd_.as<Fr>(), log_n, d.group_gen, nullptr);
-    fill_stage_tables(stream_, stage_consts_, tw_inv_.as<Fr>(), log_n, d.group_gen_inv, nullptr);
+    fill_stage_tables(stream_, stage_consts_, tw_fwd_.as<Fr>(), log_n, d.group_gen, nullptr, true);
+    fill_stage_tables(stream_, stage_consts_, tw_inv_.as<Fr>(), log_n, d.group_gen_inv, nullptr, true);
     table_log_ = log_n;
 }
 
 const Fr *NttEngine::roots_half(uint32_t log_n) {
-    ensure_tables(log_n ? log_n : 1);
+    if (log_n == 0) log_n = 1;
+    if (plain_log_ != log_n) {
+        Domain d = Domain::make(1ull << log_n);
+        tw_plain_.reserve(((size_t)1 << log_n) * sizeof(Fr));
+        fill_stage_tables(stream_, stage_consts_, tw_plain_.as<Fr>(), log_n, d.group_gen, nullptr, false);
+        plain_log_ = log_n;
+    }
     // the stage with half-size h = n/2 holds w_n^i at entries h-1 .. 2h-2
-    return tw_fwd_.as<Fr>() + (log_n ? ((size_t)1 << (log_n - 1)) - 1 : 0);
+    return tw_plain_.as<Fr>() + ((size_t)1 << (log_n - 1)) - 1;
 }
 
 const Fr *NttEngine::coset_inv_table(uint32_t log_n) {
@@ -293,7 +383,7 @@ const Fr *NttEngine::coset_inv_table(uint32_t log_n) {
     DevBuf &buf = tw_cinv_[log_n];
     buf.reserve((1ull << log_n) * sizeof(Fr));
     // c_q = (g^-1)^(n/2h): for the top stage (h = n/2) that is g^-1 itself
-    fill_stage_tables(stream_, stage_consts_, buf.as<Fr>(), log_n, d.group_gen_inv, &d.generator_inv);
+    fill_stage_tables(stream_, stage_consts_, buf.as<Fr>(), log_n, d.group_gen_inv, &d.generator_inv, true);
     return buf.as<Fr>();
 }
 
@@ -380,10 +470,10 @@ void NttEngine::transform(NttMode mode, const Fr *in, size_t len_in, Fr *out, ui
         if (threads > 1024) threads = 1024;
         if (threads < 64) threads = 64;
         const uint32_t grid = (uint32_t)(n >> tile_log);
-        const size_t lds_bytes = E * sizeof(Fr);
+        const size_t lds_bytes = E * 9 * sizeof(uint32_t);
         if (!lds_attr_set_) {
             ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
             lds_attr_set_ = true;
         }
         hipLaunchKernelGGL(ntt_pass_kernel, dim3(grid), dim3(threads), lds_bytes, stream_, a);

@@ -52,6 +52,8 @@ class NttEngine {
 
     hipStream_t stream_;
     uint32_t table_log_ = 0;
+    DevBuf tw_plain_;                   // unscaled forward table of one size, for roots_half()
+    uint32_t plain_log_ = 0;
     DevBuf tw_fwd_, tw_inv_;            // stage tables: entry h-1+i = w_{2h}^{+-i}, h = 1,2,4,...
     std::map<uint32_t, DevBuf> tw_cinv_;  // per log_n: g^{-n/2h} * w_{2h}^{-i}
     DevBuf gpow_lo_, gpow_hi_;          // g^i = hi[i >> 12] * lo[i & 4095]

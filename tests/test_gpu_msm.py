@@ -159,3 +159,43 @@ def test_msm_window_and_segment_widths(ctx, orc, window_bits, segment_bits):
         assert inf == want_inf and np.array_equal(xy, want_xy)
     finally:
         ctx.msm_set_params(0, 0)
+
+
+def test_msm_2_22_properties(ctx, orc):
+    """At the benchmark's size the oracle is too slow, so the sum is checked through properties of the group:
+    range shards add up to the whole, and the sum over s plus the sum over (r - s) is the identity."""
+    import torch
+    import zkvm_amd
+    from zkvm_amd import circuits
+    n = 1 << 22
+    base, _ = orc.g1_multiples_of_generator(1, 1 << 12)
+    pts = torch.from_numpy(base.view(np.int64)).cuda().repeat(n >> 12, 1).contiguous()
+    ctx.srs_load(pts)
+    del pts
+    sc = M.random_fr_mont(n, seed=2222)
+    sc[:7] = 0
+    sd = torch.from_numpy(sc.view(np.int64)).cuda()
+    whole = ctx.msm_partial(sd, 0)
+    xy, inf = zkvm_amd.g1_sum_to_affine(whole.reshape(1, 18))
+    assert inf == 0
+    # three unequal shards
+    cuts = [0, 1_000_003, 3 * (1 << 20) + 17, n]
+    parts = np.stack([ctx.msm_partial(sd[cuts[k]:cuts[k + 1]].contiguous(), cuts[k]) for k in range(3)])
+    xy2, inf2 = zkvm_amd.g1_sum_to_affine(parts)
+    assert inf2 == 0 and np.array_equal(xy, xy2)
+    # negated scalars: limb-wise r - s on the Montgomery residues (negation commutes with the Montgomery map)
+    r_limbs = np.array([0xffffffff00000001, 0x53bda402fffe5bfe, 0x3339d80809a1d805, 0x73eda753299d7d48], dtype=np.uint64)
+    neg = np.zeros_like(sc)
+    borrow = np.zeros(n, dtype=np.uint64)
+    for k in range(4):
+        a = np.full(n, r_limbs[k], dtype=np.uint64)
+        t = a - sc[:, k]
+        b1 = (a < sc[:, k]).astype(np.uint64)
+        t2 = t - borrow
+        b2 = (t < borrow).astype(np.uint64)
+        neg[:, k] = t2
+        borrow = b1 | b2
+    neg[(sc == 0).all(axis=1)] = 0
+    other = ctx.msm_partial(torch.from_numpy(neg.view(np.int64)).cuda(), 0)
+    _, inf3 = zkvm_amd.g1_sum_to_affine(np.stack([whole, other]))
+    assert inf3 == 1

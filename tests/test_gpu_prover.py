@@ -185,3 +185,23 @@ def test_prove_unsatisfied_circuit(ctx, orc, srs):
     assert op.prove(w, c["public_inputs"], bl)["rc"] == 2
     with pytest.raises(api.PolynomialDegreeTooLarge):
         gp.prove(w.reshape(-1, 4), c["public_inputs"], bl)
+
+
+def test_prove_2_14(ctx, orc):
+    """A circuit large enough for multi-pass transforms on the 8n = 2^17 domain and several sort slices per range."""
+    from zkvm_amd import api, circuits
+    n = 1 << 14
+    tau = M.random_fr_mont(1, seed=78)[0]
+    srs14, inf = orc.srs_powers(orc.g1_generator(), tau, n + 7)
+    assert not inf.any()
+    c = _circuit(orc, n, seed=21)
+    ctx.srs_load(srs14)
+    gp = api.Prover(ctx, n, c["constraints"], c["selectors"].reshape(-1, 4), b"parity-14", c["pi_indexes"])
+    op = orc.Prover(n, c["constraints"], c["selectors"], srs14, b"parity-14", c["pi_indexes"], threads=16)
+    assert op.preprocess_rc == 0
+    bl = circuits.random_blinders(21)
+    want = op.prove(c["wires"], c["public_inputs"], bl)
+    assert want["rc"] == 0
+    got = gp.prove(c["wires"].reshape(-1, 4), c["public_inputs"], bl)
+    for key in ("challenges", "evals", "comms_inf", "comms"):
+        assert np.array_equal(got[key], want[key]), key

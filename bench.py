@@ -195,18 +195,6 @@ def cpu_baseline_ntt():
 MSM_LOG = 22
 
 
-def synthetic_points(ctx, n, device):
-    """n distinct G1 points for throughput runs: k_i * G for pseudo-random 64-bit k_i would need n scalar
-    multiplications; instead the oracle makes 2^12 consecutive multiples of G on the CPU and the device table is
-    filled by tiling them (duplicates do not change the work per addition: the formulas are complete)."""
-    import torch
-    from oracle import pyoracle as orc
-    base, _ = orc.g1_multiples_of_generator(1, 1 << 12)
-    reps = (n + (1 << 12) - 1) >> 12
-    t = to_dev(base, device).repeat(reps, 1)[:n].contiguous()
-    return t
-
-
 def run_msm(args, rank, world, local, device):
     import torch
     import zkvm_amd
@@ -214,9 +202,16 @@ def run_msm(args, rank, world, local, device):
     from zkvm_amd import sharding
     n_total = 1 << args.log_points
     base, shard = sharding.shard_range(n_total, rank, world)
-    pts = synthetic_points(ctx, n_total, device)
-    ctx.srs_load(pts[base:base + shard].contiguous())
-    del pts
+    # this rank's range of the SRS: tau^(base + i) * G = tau^i * (tau^base * G)
+    from zkvm_amd import circuits
+    tau = circuits.seeded_tau()
+    g = circuits.g1_generator_limbs()
+    if base:
+        tau_int = int.from_bytes(tau.tobytes(), "little") * circuits.MONT_INV % circuits.R_MOD
+        shift = circuits.ints_to_limbs([circuits.to_mont(pow(tau_int, base, circuits.R_MOD))])[0]
+        ctx.srs_setup(shift, g, 2)
+        g = ctx.srs_export(2)[0][1]
+    ctx.srs_setup(tau, g, shard)
     scalars = to_dev(random_fr(n_total, 3)[base:base + shard], device)   # seed 3: uniform scalars
 
     def step():
@@ -292,7 +287,10 @@ def run_prove(args, rank, world, local, device):
     log_n = args.log_gates
     n = 1 << log_n
     ctx = zkvm_amd.Context(local)
-    ctx.srs_load(tiled_srs(n + 7, device))
+    t0 = time.perf_counter()
+    ctx.srs_setup(circuits.seeded_tau(), circuits.g1_generator_limbs(), n + 7)   # tau^i * G, generated on the device
+    ctx.sync()
+    t_srs = time.perf_counter() - t0
     t0 = time.perf_counter()
     circ = circuits.arithmetic_circuit(n, seed=5 + rank)
     circuits.fill_sigma_rows(circ, ctx)
@@ -319,7 +317,7 @@ def run_prove(args, rank, world, local, device):
         timed = prover.prove(wires, circ["public_inputs"], blinders, timings=True)
         assert np.array_equal(timed["comms"], proof["comms"]) and np.array_equal(timed["evals"], proof["evals"])
         out["phase_ms"] = {k: round(v, 3) for k, v in timed["timings_ms"].items()}
-        out["setup_s"] = {"circuit_host": round(t_circ, 2), "key_preprocess_gpu": round(t_key, 3)}
+        out["setup_s"] = {"srs_gpu": round(t_srs, 3), "circuit_host": round(t_circ, 2), "key_preprocess_gpu": round(t_key, 3)}
         out["proof_digest"] = {"a_comm_x0": hex(int(proof["comms"][0][0])), "z_eval_0": hex(int(proof["evals"][14][0]))}
         # dominant kernel: msm_accumulate_kernel of the 11 commitments; HIP events on the library's stream around the
         # phases of one n-point commitment
@@ -418,7 +416,7 @@ def main():
     if rank == 0:
         line.update({"value": round(value, 3), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                      "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "vs_baseline": None,
-                     "data": "synthetic (seeded uniform Fr; SRS-shaped point table)"})
+                     "data": "synthetic (seeded circuits and scalars; SRS = powers of a seeded tau times the G1 generator)"})
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = (cpu_baseline_prove(args.log_gates) if args.workload == "prove" else

@@ -97,6 +97,13 @@ int zkgpu_srs_load(zkgpu_ctx *ctx, const uint64_t *xy, const uint8_t *infinity, 
 /* As above from a device buffer of n_points x 96 bytes (copied). */
 int zkgpu_srs_load_dev(zkgpu_ctx *ctx, const void *xy_dev, size_t n_points);
 
+/* PublicParameters::setup (plonk/src/commitment_scheme/kzg10/srs.rs:40-71) with the two random draws made explicit:
+ * powers_of_g[i] = tau^i * g for i < n_points, generated on the device and kept as the context's SRS (n_points =
+ * max_degree + 6 + 1 in the reference's terms).  `g_xy` is an affine point in the layout of zkgpu_srs_load. */
+int zkgpu_srs_setup(zkgpu_ctx *ctx, const uint64_t tau[4], const uint64_t g_xy[12], size_t n_points);
+/* Copies the first n points of the resident SRS back to the host (x | y, and the infinity flags when not NULL). */
+int zkgpu_srs_export(zkgpu_ctx *ctx, uint64_t *out_xy, uint8_t *out_infinity, size_t n);
+
 /* Tuning knobs of the bucket method, for experiments and tests: the signed-digit window width used by the NEXT
  * zkgpu_srs_load* (4..22, 0 = chosen from the table size) and the log2 segment width of the bucket reduction
  * (1..6, 0 = default).  Results do not depend on them. */

@@ -1,0 +1,78 @@
+"""The reference verifier's final equation (plonk/src/proof_system/proof.rs:179-404) for arithmetic-only circuits with
+one public input at gate 0, with the pairing replaced by the known trapdoor of a test SRS:
+e(A, [tau]_2) = e(B, [1]_2)  <=>  tau * A = B in G1.  All arithmetic is Python big integers (tests/model.py)."""
+import model as M
+
+R = M.R_MOD
+K = (1, 7, 13, 17)
+COMM_NAMES = ["a_comm", "b_comm", "c_comm", "d_comm", "z_comm", "t_low_comm", "t_mid_comm", "t_high_comm",
+              "t_fourth_comm", "w_z_chall_comm", "w_z_chall_w_comm"]
+EVAL_NAMES = ["a_eval", "b_eval", "c_eval", "d_eval", "a_w_eval", "b_w_eval", "d_w_eval", "q_arith_eval", "q_c_eval",
+              "q_l_eval", "q_r_eval", "s_sigma_1_eval", "s_sigma_2_eval", "s_sigma_3_eval", "z_eval"]
+SEL_NAMES = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic", "q_fixed_group_add",
+             "q_variable_group_add", "s_sigma_1", "s_sigma_2", "s_sigma_3", "s_sigma_4"]
+
+
+def _ints(arr):
+    import numpy as np
+    return M.fr_vec_from_mont(np.asarray(arr, dtype=np.uint64).reshape(-1, 4))
+
+
+def _pt(xy, inf=0):
+    return M.affine_from_limbs(xy, inf)
+
+
+def verifier_sides(n, proof, sel_xy, sel_inf, public_input0, tau, g_xy, u=None, tamper=0):
+    """-> (left, right) of tau * (W_z + u W_zw) = z W_z + u z w W_zw + F - E; equal for a valid proof."""
+    G = _pt(g_xy)
+    comm = {name: _pt(proof["comms"][i], proof["comms_inf"][i]) for i, name in enumerate(COMM_NAMES)}
+    e = dict(zip(EVAL_NAMES, _ints(proof["evals"])))
+    beta, gamma, alpha, _, _, _, _, z, v, v_w = _ints(proof["challenges"])
+    vk = {name: _pt(sel_xy[i], sel_inf[i]) for i, name in enumerate(SEL_NAMES)}
+    if u is None:
+        u = M.random_fr_ints(1, 1234)[0]       # the verifier's own challenge; the equation must hold for any value
+    om = M.domain_root(n)
+
+    zh = (pow(z, n, R) - 1) % R
+    l1 = zh * pow(n * (z - 1) % R, -1, R) % R
+    # public input polynomial at z (barycentric form, proof.rs:511-561); the only public input sits at gate 0
+    pi_eval = public_input0 * zh * pow(n * (z - 1) % R, -1, R) % R
+
+    # linearization commitment (proof.rs:408-496, widget/arithmetic/verifierkey.rs:91-117,
+    # widget/permutation/verifierkey.rs); the range/logic/ecc selectors of these circuits are identically zero
+    qa = e["q_arith_eval"]
+    terms = [(e["a_eval"] * e["b_eval"] * qa, vk["q_m"]), (e["a_eval"] * qa, vk["q_l"]), (e["b_eval"] * qa, vk["q_r"]),
+             (e["c_eval"] * qa, vk["q_o"]), (e["d_eval"] * qa, vk["q_f"]), (qa, vk["q_c"])]
+    for name in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add"):
+        assert vk[name] is None
+    ident = (e["a_eval"] + beta * z + gamma) * (e["b_eval"] + beta * K[1] * z + gamma) \
+        * (e["c_eval"] + beta * K[2] * z + gamma) * (e["d_eval"] + beta * K[3] * z + gamma) * alpha % R
+    terms.append(((ident + l1 * alpha * alpha + u) % R, comm["z_comm"]))
+    copy = (e["a_eval"] + beta * e["s_sigma_1_eval"] + gamma) * (e["b_eval"] + beta * e["s_sigma_2_eval"] + gamma) \
+        * (e["c_eval"] + beta * e["s_sigma_3_eval"] + gamma) * beta * e["z_eval"] * alpha % R
+    terms.append(((-copy) % R, vk["s_sigma_4"]))
+    mzh = (-zh) % R
+    terms += [(mzh, comm["t_low_comm"]), (pow(z, n, R) * mzh % R, comm["t_mid_comm"]),
+              (pow(z, 2 * n, R) * mzh % R, comm["t_high_comm"]), (pow(z, 3 * n, R) * mzh % R, comm["t_fourth_comm"])]
+    lin = M.ec_msm([p for _, p in terms], [s for s, _ in terms])
+
+    r0 = (pi_eval - l1 * alpha * alpha
+          - alpha * (e["a_eval"] + beta * e["s_sigma_1_eval"] + gamma) * (e["b_eval"] + beta * e["s_sigma_2_eval"] + gamma)
+          * (e["c_eval"] + beta * e["s_sigma_3_eval"] + gamma) * (e["d_eval"] + gamma) * e["z_eval"]) % R
+    vs = [pow(v, i, R) for i in range(1, 8)]
+    vs += [v_w * u % R, v_w * v_w * u % R, v_w * v_w * v_w * u % R]
+    e_list = [e[k] for k in ("a_eval", "b_eval", "c_eval", "d_eval", "s_sigma_1_eval", "s_sigma_2_eval", "s_sigma_3_eval",
+                             "a_w_eval", "b_w_eval", "d_w_eval")]
+    e_scalar = (sum(x * y for x, y in zip(e_list, vs)) - r0 + u * e["z_eval"] + tamper) % R
+    sc = vs[:7]
+    sc[0] = (sc[0] + vs[7]) % R
+    sc[1] = (sc[1] + vs[8]) % R
+    sc[3] = (sc[3] + vs[9]) % R
+    pts = [comm["a_comm"], comm["b_comm"], comm["c_comm"], comm["d_comm"], vk["s_sigma_1"], vk["s_sigma_2"], vk["s_sigma_3"]]
+    F = M.ec_add(M.ec_msm(pts, sc), lin)
+    E = M.ec_mul(G, e_scalar)
+    wz, wzw = comm["w_z_chall_comm"], comm["w_z_chall_w_comm"]
+    neg_e = None if E is None else (E[0], (-E[1]) % M.P_MOD)
+    left = M.ec_mul(M.ec_add(wz, M.ec_mul(wzw, u)), tau)
+    right = M.ec_add(M.ec_add(M.ec_mul(wz, z), M.ec_mul(wzw, u * z * om % R)), M.ec_add(F, neg_e))
+    return left, right

@@ -1,0 +1,86 @@
+"""GPU parity of the SRS generation (PublicParameters::setup, kzg10/srs.rs:40-71) and a full-size proof checked through
+the reference verifier's equation under the SRS trapdoor."""
+import numpy as np
+import pytest
+
+import model as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import zkvm_amd
+    c = zkvm_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("tau_kind", ["random", "zero", "one", "minus_one"])
+def test_srs_setup_matches_oracle(ctx, orc, tau_kind):
+    n = 300
+    tau = {"random": M.random_fr_mont(1, seed=5)[0], "zero": M.fr_to_mont(0), "one": M.fr_to_mont(1),
+           "minus_one": M.fr_to_mont(M.R_MOD - 1)}[tau_kind]
+    g = orc.g1_generator()
+    gxy, _ = orc.g1_to_affine(g)
+    want_xy, want_inf = orc.srs_powers(g, tau, n)
+    ctx.srs_setup(tau, gxy, n)
+    got_xy, got_inf = ctx.srs_export(n)
+    assert np.array_equal(got_inf, want_inf)
+    assert np.array_equal(got_xy, want_xy)
+    # the generated table is live: a commitment over it matches the oracle's over the same points
+    sc = M.random_fr_mont(n, seed=6)
+    xy, inf = ctx.msm(sc)
+    w_xy, w_inf = orc.g1_to_affine(orc.msm(want_xy, sc, inf=want_inf, threads=4))
+    assert inf == int(w_inf) and (inf or np.array_equal(xy, w_xy))
+
+
+def test_srs_setup_other_base_point(ctx, orc):
+    pts, _ = orc.g1_multiples_of_generator(12345, 1)
+    g = np.concatenate([pts[0], M.fq_to_mont(1)])
+    tau = M.random_fr_mont(1, seed=8)[0]
+    want_xy, want_inf = orc.srs_powers(g, tau, 40)
+    ctx.srs_setup(tau, pts[0], 40)
+    got_xy, got_inf = ctx.srs_export(40)
+    assert np.array_equal(got_xy, want_xy) and not got_inf.any()
+
+
+def test_prove_2_20_satisfies_verifier_equation(ctx, orc):
+    """The benchmark's size: the oracle would need minutes, so the proof is checked the way the reference checks
+    proofs — by the verifier's equation — with the pairing replaced by the trapdoor of the generated SRS."""
+    import torch
+    import plonk_check
+    from zkvm_amd import api, circuits
+    n = 1 << 20
+    tau = M.random_fr_mont(1, seed=2020)[0]
+    gxy, _ = orc.g1_to_affine(orc.g1_generator())
+    ctx.srs_setup(tau, gxy, n + 7)
+    c = circuits.arithmetic_circuit(n, seed=20)
+    circuits.fill_sigma_rows(c, ctx)
+    gp = api.Prover(ctx, n, c["constraints"], c["selectors"].reshape(-1, 4), b"full-size", c["pi_indexes"])
+    sxy, sinf = gp.selector_commitments()
+    c["selectors"] = None
+    wires = torch.from_numpy(c["wires"].reshape(-1, 4).view(np.int64)).cuda()
+    proof = gp.prove(wires, c["public_inputs"], circuits.random_blinders(20))
+    pi0 = M.fr_from_mont(c["public_inputs"][0])
+    tau_int = M.fr_from_mont(tau)
+    left, right = plonk_check.verifier_sides(n, proof, sxy, sinf, pi0, tau_int, gxy)
+    assert left == right
+    left, right = plonk_check.verifier_sides(n, proof, sxy, sinf, pi0, tau_int, gxy, tamper=1)
+    assert left != right
+
+
+def test_srs_range_from_shifted_base(ctx, orc):
+    """A rank of a sharded commitment generates its own SRS range: tau^(base + i) G = tau^i (tau^base G)."""
+    from zkvm_amd import circuits
+    tau = circuits.seeded_tau()
+    g = circuits.g1_generator_limbs()
+    base, count = 37, 50
+    tau_int = M.fr_from_mont(tau)
+    shift = M.fr_to_mont(pow(tau_int, base, M.R_MOD))
+    ctx.srs_setup(shift, g, 2)
+    g_shifted = ctx.srs_export(2)[0][1]
+    ctx.srs_setup(tau, g_shifted, count)
+    got, _ = ctx.srs_export(count)
+    want, _ = orc.srs_powers(orc.g1_generator(), tau, base + count)
+    assert np.array_equal(got, want[base:])

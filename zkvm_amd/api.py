@@ -122,6 +122,17 @@ class Context:
         self._check(self._lib.zkgpu_srs_load(self._h, pts.ctypes.data, inf.ctypes.data if inf is not None else None,
                                              pts.shape[0]))
 
+    def srs_setup(self, tau, g_xy, n_points):
+        """PublicParameters::setup on the device: SRS[i] = tau^i * g."""
+        t, g = _np_u64(tau, 4), _np_u64(g_xy, 12)
+        self._check(self._lib.zkgpu_srs_setup(self._h, t.ctypes.data, g.ctypes.data, int(n_points)))
+
+    def srs_export(self, n):
+        xy = np.zeros((n, 12), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8)
+        self._check(self._lib.zkgpu_srs_export(self._h, xy.ctypes.data if n else None, inf.ctypes.data if n else None, n))
+        return xy, inf
+
     def msm_set_params(self, window_bits=0, segment_bits=0):
         """Tuning knobs (0 = automatic); window_bits applies to the next srs_load."""
         self._check(self._lib.zkgpu_msm_set_params(self._h, int(window_bits), int(segment_bits)))

@@ -19,6 +19,25 @@ SEL = {n: i for i, n in enumerate(["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_
                                    "s_sigma_4"])}
 
 
+# BLS12-381 base field and the standard G1 generator (coset-bls12_381/src/g1.rs:218-238), as integers
+P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+G1_X = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
+G1_Y = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+
+
+def g1_generator_limbs():
+    """(12,) uint64: x | y of the generator in the Montgomery form (radix 2^384) the library's point tables use."""
+    vals = [(G1_X << 384) % P_MOD, (G1_Y << 384) % P_MOD]
+    buf = b"".join(v.to_bytes(48, "little") for v in vals)
+    return np.frombuffer(buf, dtype=np.uint64).copy()
+
+
+def seeded_tau(seed=7):
+    """A fixed SRS trapdoor for synthetic parameters (never use a known trapdoor outside tests and benchmarks)."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x7a0))
+    return random_mont(rng, 1)[0]
+
+
 def to_mont(v):
     return (v % R_MOD) * MONT % R_MOD
 

@@ -211,6 +211,24 @@ int zkgpu_ntt_set_params(zkgpu_ctx *ctx, uint32_t tile_log, uint32_t elems_per_t
     });
 }
 
+int zkgpu_srs_setup(zkgpu_ctx *ctx, const uint64_t tau[4], const uint64_t g_xy[12], size_t n_points) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(tau && g_xy, ZKGPU_ERR_INVALID_ARG, "srs_setup: null argument");
+        Fr t;
+        G1Affine g;
+        memcpy(&t, tau, sizeof t);
+        memcpy(&g, g_xy, sizeof g);
+        ctx->msm->setup_powers(t, g, n_points);
+    });
+}
+
+int zkgpu_srs_export(zkgpu_ctx *ctx, uint64_t *out_xy, uint8_t *out_infinity, size_t n) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(out_xy || n == 0, ZKGPU_ERR_INVALID_ARG, "srs_export: null output");
+        ctx->msm->export_points(out_xy, out_infinity, n);
+    });
+}
+
 int zkgpu_msm_set_params(zkgpu_ctx *ctx, uint32_t window_bits, uint32_t segment_bits) {
     return guarded(ctx, [&] {
         ZK_REQUIRE(window_bits == 0 || (window_bits >= 4 && window_bits <= 22), ZKGPU_ERR_INVALID_ARG,

@@ -23,6 +23,7 @@
 // commitment compared by the tests, is the same group element.
 #include "msm.hpp"
 #include "fq28.cuh"
+#include <cstring>
 
 namespace zk {
 
@@ -655,6 +656,41 @@ __global__ void msm_mark_infinity_kernel(G1Affine *points, const uint8_t *inf, u
     for (int k = 0; k < 6; k++) q[k] = make_uint4(0, 0, 0, 0);
 }
 
+// ---- SRS generation ----------------------------------------------------------------------------------------------
+// out[i] = tau^i * g, affine, reference form: PublicParameters::setup (plonk/src/commitment_scheme/kzg10/srs.rs:40-71)
+// computes the same points as one full scalar multiplication per power followed by batch_normalize.  Thread i
+// raises tau to i (32 squarings), leaves Montgomery form and runs double-and-add on the extended Jacobian
+// accumulator; the affine conversion spends one inversion per point.
+__global__ void __launch_bounds__(256) msm_powers_kernel(Fr tau, G1Affine g, uint32_t n, G1Affine *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr e = Fr::one(), b = tau;
+    for (uint32_t k = i; k; k >>= 1) {
+        if (k & 1) e = Fr::mul(e, b);
+        b = Fr::sqr(b);
+    }
+    e = Fr::from_mont(e);
+    const G1Affine28 g28 = affine_to_28(g);
+    G1Xyzz acc = G1Xyzz::identity();
+    for (int bit = 254; bit >= 0; bit--) {
+        if (!acc.is_identity()) acc = xyzz_double(acc);
+        if ((e.v[bit >> 5] >> (bit & 31)) & 1u) acc = xyzz_add_mixed(acc, g28, false);
+    }
+    G1Affine r;
+    if (acc.is_identity()) {
+        r.x = Fq::zero();
+        r.y = Fq::zero();
+    } else {
+        const G1Proj p = xyzz_to_proj(acc);
+        const Fq zinv = Fq::inv(p.z);
+        r.x = Fq::mul(p.x, zinv);
+        r.y = Fq::mul(p.y, zinv);
+    }
+    uint4 *q = reinterpret_cast<uint4 *>(out + i);
+    gstore_fq(q, r.x);
+    gstore_fq(q + 3, r.y);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 MsmEngine::~MsmEngine() {
     DevBuf *all[] = {&points_, &counts_, &offsets_, &cursor_, &sorted_, &buckets_, &block_sums_, &tasks_, &partials_,
@@ -726,6 +762,34 @@ void MsmEngine::load_points(const uint64_t *xy_host, const uint8_t *infinity_hos
     }
     ZK_HIP(hipStreamSynchronize(stream_));
     build_table(n);
+}
+
+void MsmEngine::setup_powers(const Fr &tau, const G1Affine &g, size_t n) {
+    ZK_REQUIRE(n >= 1 && n < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "srs_setup: bad point count");
+    n_points_ = 0;
+    const uint32_t c = window_override_ ? window_override_ : choose_window(n);
+    points_.reserve((size_t)(255 / c + 1) * n * sizeof(G1Affine) + 16);
+    hipLaunchKernelGGL(msm_powers_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, tau, g, (uint32_t)n,
+                       points_.as<G1Affine>());
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(stream_));
+    build_table(n);
+}
+
+void MsmEngine::export_points(uint64_t *xy_host, uint8_t *infinity_host, size_t n) {
+    ZK_REQUIRE(n <= n_points_, ZKGPU_ERR_INVALID_ARG, "srs_export: more points than loaded");
+    if (!n) return;
+    ZK_HIP(hipMemcpyAsync(xy_host, points_.p, n * sizeof(G1Affine), hipMemcpyDeviceToHost, stream_));
+    ZK_HIP(hipStreamSynchronize(stream_));
+    for (size_t i = 0; i < n; i++) {
+        bool inf = true;
+        for (int k = 0; k < 12; k++) inf = inf && xy_host[12 * i + k] == 0;
+        if (infinity_host) infinity_host[i] = inf ? 1 : 0;
+        if (inf) {   // the reference's affine identity is (0, 1, infinity)
+            Fq one = Fq::one();
+            memcpy(xy_host + 12 * i + 6, one.v, 48);
+        }
+    }
 }
 
 void MsmEngine::load_points_device(const void *xy_dev, size_t n) {

@@ -19,6 +19,10 @@ class MsmEngine {
     void load_points(const uint64_t *xy_host, const uint8_t *infinity_host, size_t n);
     // Same, from a device buffer of n x 96 bytes (copied; infinity = all-zero x and y).
     void load_points_device(const void *xy_dev, size_t n);
+    // Generates the table instead of uploading it: points[i] = tau^i * g (PublicParameters::setup, kzg10/srs.rs:40-71).
+    void setup_powers(const Fr &tau, const G1Affine &g, size_t n);
+    // Copies the first n loaded points back in the reference form (identity = (0, 1) + flag).
+    void export_points(uint64_t *xy_host, uint8_t *infinity_host, size_t n);
     size_t n_points() const { return n_points_; }
 
     // sum_i scalars[i] * points[base + i], i < n.  `scalars_dev` holds n Fr elements in Montgomery form

@@ -104,6 +104,15 @@ int zkgpu_srs_setup(zkgpu_ctx *ctx, const uint64_t tau[4], const uint64_t g_xy[1
 /* Copies the first n points of the resident SRS back to the host (x | y, and the infinity flags when not NULL). */
 int zkgpu_srs_export(zkgpu_ctx *ctx, uint64_t *out_xy, uint8_t *out_infinity, size_t n);
 
+/* CommitKey::from_slice_unchecked / to_raw_var_bytes (plonk/src/commitment_scheme/kzg10/key.rs:38-66): a u64
+ * little-endian point count followed by 97 bytes per point (x and y as six little-endian u64 Montgomery limbs each,
+ * then the infinity flag; coset-bls12_381/src/g1/coset.rs:8-48).  In a PublicParameters::to_raw_var_bytes file the
+ * commit key starts after the 240-byte OpeningKey (srs.rs:73-79).  As the reference, the loader takes
+ * min(count, whole points present); zkgpu_srs_export_raw writes the resident SRS in the same format
+ * (8 + 97 * n_points bytes; *written receives that size, and nothing is written when cap is smaller). */
+int zkgpu_srs_load_raw(zkgpu_ctx *ctx, const uint8_t *bytes, size_t len);
+int zkgpu_srs_export_raw(zkgpu_ctx *ctx, uint8_t *out, size_t cap, size_t *written);
+
 /* Tuning knobs of the bucket method, for experiments and tests: the signed-digit window width used by the NEXT
  * zkgpu_srs_load* (4..22, 0 = chosen from the table size) and the log2 segment width of the bucket reduction
  * (1..6, 0 = default).  Results do not depend on them. */

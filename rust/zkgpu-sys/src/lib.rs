@@ -62,6 +62,8 @@ extern "C" {
     pub fn zkgpu_srs_load_dev(ctx: *mut zkgpu_ctx, xy_dev: *const c_void, n_points: usize) -> c_int;
     pub fn zkgpu_srs_setup(ctx: *mut zkgpu_ctx, tau: *const u64, g_xy: *const u64, n_points: usize) -> c_int;
     pub fn zkgpu_srs_export(ctx: *mut zkgpu_ctx, out_xy: *mut u64, out_infinity: *mut u8, n: usize) -> c_int;
+    pub fn zkgpu_srs_load_raw(ctx: *mut zkgpu_ctx, bytes: *const u8, len: usize) -> c_int;
+    pub fn zkgpu_srs_export_raw(ctx: *mut zkgpu_ctx, out: *mut u8, cap: usize, written: *mut usize) -> c_int;
     pub fn zkgpu_msm_set_params(ctx: *mut zkgpu_ctx, window_bits: u32, segment_bits: u32) -> c_int;
     pub fn zkgpu_msm_get_params(ctx: *mut zkgpu_ctx, window_bits: *mut u32, n_windows: *mut u32) -> c_int;
     pub fn zkgpu_msm(ctx: *mut zkgpu_ctx, scalars: *const u64, n: usize, out_xy: *mut u64, out_infinity: *mut u8) -> c_int;

@@ -84,3 +84,36 @@ def test_srs_range_from_shifted_base(ctx, orc):
     got, _ = ctx.srs_export(count)
     want, _ = orc.srs_powers(orc.g1_generator(), tau, base + count)
     assert np.array_equal(got, want[base:])
+
+
+def test_srs_raw_bytes_round_trip(ctx, orc):
+    """The reference's raw CommitKey encoding: u64 count, then x | y limbs and the infinity byte per point."""
+    n = 33
+    pts, _ = orc.g1_multiples_of_generator(5, n)
+    inf = np.zeros(n, np.uint8)
+    inf[4] = 1
+    raw = bytearray(int(n).to_bytes(8, "little"))
+    for i in range(n):
+        raw += pts[i].tobytes() + bytes([int(inf[i])])
+    ctx.srs_load_raw(bytes(raw))
+    xy, got_inf = ctx.srs_export(n)
+    assert np.array_equal(got_inf, inf)
+    keep = inf == 0
+    assert np.array_equal(xy[keep], pts[keep])
+    out = ctx.srs_export_raw()
+    assert len(out) == 8 + 97 * n and out[:8] == raw[:8]
+    for i in range(n):
+        rec = out[8 + 97 * i: 8 + 97 * (i + 1)]
+        assert rec[96] == inf[i]
+        if not inf[i]:
+            assert rec[:96] == pts[i].tobytes()
+    # a count larger than the points present is cut to what is there; trailing partial points are ignored
+    ctx.srs_load_raw(int(1000).to_bytes(8, "little") + bytes(raw[8:8 + 97 * 7 + 50]))
+    xy, _ = ctx.srs_export(7)
+    assert np.array_equal(xy[:4], pts[:4])
+    with pytest.raises(Exception):
+        ctx.srs_export(8)
+    sc = M.random_fr_mont(7, seed=3)
+    got = ctx.msm(sc)
+    want = orc.g1_to_affine(orc.msm(pts[:7], sc, inf=inf[:7]))
+    assert got[1] == int(want[1]) and np.array_equal(got[0], want[0])

@@ -63,6 +63,8 @@ SIGNATURES = {
     "zkgpu_ntt_set_params": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "zkgpu_srs_setup": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "zkgpu_srs_export": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "zkgpu_srs_load_raw": (C.c_int, [_P, _P, C.c_size_t]),
+    "zkgpu_srs_export_raw": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "zkgpu_msm_get_params": (C.c_int, [_P, _P, _P]),
     "zkgpu_msm_profile_dev": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "zkgpu_msm_set_params": (C.c_int, [_P, C.c_uint32, C.c_uint32]),

@@ -133,6 +133,19 @@ class Context:
         self._check(self._lib.zkgpu_srs_export(self._h, xy.ctypes.data if n else None, inf.ctypes.data if n else None, n))
         return xy, inf
 
+    def srs_load_raw(self, data):
+        """CommitKey::from_slice_unchecked: u64 count + 97 bytes per point."""
+        buf = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+        self._check(self._lib.zkgpu_srs_load_raw(self._h, buf.ctypes.data, buf.size))
+
+    def srs_export_raw(self):
+        """CommitKey::to_raw_var_bytes of the resident SRS."""
+        need = C.c_size_t(0)
+        self._check(self._lib.zkgpu_srs_export_raw(self._h, None, 0, C.byref(need)))
+        out = np.zeros(need.value, dtype=np.uint8)
+        self._check(self._lib.zkgpu_srs_export_raw(self._h, out.ctypes.data, out.size, C.byref(need)))
+        return bytes(out)
+
     def msm_set_params(self, window_bits=0, segment_bits=0):
         """Tuning knobs (0 = automatic); window_bits applies to the next srs_load."""
         self._check(self._lib.zkgpu_msm_set_params(self._h, int(window_bits), int(segment_bits)))

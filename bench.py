@@ -63,16 +63,27 @@ def to_dev(a, device):
     return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(device)
 
 
+# ZKGPU_BENCH_REHEARSAL=1 rehearses the multi-rank flow on a machine with ONE GPU: all ranks share cuda:0 and the
+# collectives run over gloo on host tensors.  Its numbers mean nothing; it exists to exercise the N > 1 code path.
+REHEARSAL = os.environ.get("ZKGPU_BENCH_REHEARSAL") == "1"
+
+
+def comm_device(device):
+    return None if REHEARSAL else device
+
+
 def dist_setup(n_gpus):
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if REHEARSAL:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if REHEARSAL else "nccl", rank=rank, world_size=world)
     assert world == n_gpus, "launch with torch.distributed.run --nproc-per-node %d" % n_gpus
     return rank, world, local
 
@@ -90,7 +101,7 @@ def max_over_ranks(value, world, device):
     if world == 1:
         return value
     import torch.distributed as dist
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=comm_device(device) or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -215,7 +226,7 @@ def run_msm(args, rank, world, local, device):
     scalars = to_dev(random_fr(n_total, 3)[base:base + shard], device)   # seed 3: uniform scalars
 
     def step():
-        return sharding.sharded_msm(ctx, scalars, device)
+        return sharding.sharded_msm(ctx, scalars, comm_device(device))
 
     for _ in range(max(args.warmup, 1)):
         step()
@@ -287,12 +298,20 @@ def run_prove(args, rank, world, local, device):
     log_n = args.log_gates
     n = 1 << log_n
     ctx = zkvm_amd.Context(local)
+    sharded = args.sharded and world > 1
     t0 = time.perf_counter()
-    ctx.srs_setup(circuits.seeded_tau(), circuits.g1_generator_limbs(), n + 7)   # tau^i * G, generated on the device
+    if sharded:
+        # one proof at a time on all GPUs: every rank holds a range of the SRS and sums its share of each commitment
+        from zkvm_amd import sharding
+        base, count = sharding.shard_range(n + 7, rank, world)
+        sharding.srs_setup_range(ctx, circuits.seeded_tau(), circuits.g1_generator_limbs(), base, count)
+        sharding.enable_prover_sharding(ctx, base, n + 7, comm_device(device))
+    else:
+        ctx.srs_setup(circuits.seeded_tau(), circuits.g1_generator_limbs(), n + 7)   # tau^i * G, generated on the device
     ctx.sync()
     t_srs = time.perf_counter() - t0
     t0 = time.perf_counter()
-    circ = circuits.arithmetic_circuit(n, seed=5 + rank)
+    circ = circuits.arithmetic_circuit(n, seed=5 if sharded else 5 + rank)
     circuits.fill_sigma_rows(circ, ctx)
     t_circ = time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -313,15 +332,18 @@ def run_prove(args, rank, world, local, device):
     barrier(world, device)
     elapsed = max_over_ranks(time.perf_counter() - t0, world, device)
     out = {}
-    if rank == 0:
+    timed = None
+    if sharded or rank == 0:      # a sharded proof is collective: every rank takes part
         timed = prover.prove(wires, circ["public_inputs"], blinders, timings=True)
+    if rank == 0:
         assert np.array_equal(timed["comms"], proof["comms"]) and np.array_equal(timed["evals"], proof["evals"])
         out["phase_ms"] = {k: round(v, 3) for k, v in timed["timings_ms"].items()}
         out["setup_s"] = {"srs_gpu": round(t_srs, 3), "circuit_host": round(t_circ, 2), "key_preprocess_gpu": round(t_key, 3)}
         out["proof_digest"] = {"a_comm_x0": hex(int(proof["comms"][0][0])), "z_eval_0": hex(int(proof["evals"][14][0]))}
         # dominant kernel: msm_accumulate_kernel of the 11 commitments; HIP events on the library's stream around the
         # phases of one n-point commitment
-        sc = to_dev(random_fr(n, 3), device)
+        n_local = count if sharded else n      # points this GPU holds
+        sc = to_dev(random_fr(n_local, 3), device)
         reps = 5
         ctx.msm_kernels(sc)
         ctx.sync()
@@ -334,7 +356,8 @@ def run_prove(args, rank, world, local, device):
         out["msm_2^%d_phase_ms" % log_n] = {k: round(sum(p[k] for p in phases) / reps, 3) for k in phases[0]}
         out["_acc_ms"] = sum(p["accumulate"] for p in phases) / reps
         out["_windows"] = ctx.msm_get_params()[1]
-    value = world * args.steps / elapsed
+        out["_msm_points"] = n_local
+    value = (1 if sharded else world) * args.steps / elapsed
     return value, elapsed, out, ctx
 
 
@@ -367,6 +390,9 @@ def main():
     ap.add_argument("--workload", default="prove", choices=["prove", "ntt", "msm"])
     ap.add_argument("--log-gates", type=int, default=PROVE_LOG)
     ap.add_argument("--log-points", type=int, default=MSM_LOG)
+    ap.add_argument("--sharded", action="store_true",
+                    help="prove workload on N > 1 GPUs: one proof at a time with point-range sharded commitments "
+                         "(strong scaling) instead of independent proofs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -382,15 +408,18 @@ def main():
                 "config": {"workload": "full PLONK prove, 2^%d gates (wire commits, permutation Z, quotient over the 8n "
                                        "coset, linearization, openings), bit-exact vs the CPU prover" % args.log_gates,
                            "n": 1 << args.log_gates, "parallelism": "independent proofs per GPU"}}
+        if args.sharded and world > 1:
+            line["scaling"] = "strong"
+            line["config"]["parallelism"] = ("one proof on %d GPUs: SRS point ranges per GPU, 144-byte partial sums "
+                                             "all-gathered over RCCL per commitment batch, the rest replicated" % world)
         if rank == 0:
             acc_ms = extra.pop("_acc_ms")
             windows = extra.pop("_windows")
-            n = 1 << args.log_gates
+            n = extra.pop("_msm_points")
             alg = 128.0 * n            # every point (96 B) and scalar (32 B) once
             achieved = alg / (acc_ms * 1e-3) / 1e9
             products = 10.0 * n * windows / (acc_ms * 1e-3) / 1e9    # 8 products + 2 squarings per mixed addition
-            extra["roofline"] = {"bound": "hbm", "kernel": "msm_accumulate_kernel of one 2^%d-point commitment (11 per proof)"
-                                                           % args.log_gates,
+            extra["roofline"] = {"bound": "hbm", "kernel": "msm_accumulate_kernel of one %d-point commitment (11 per proof)" % n,
                                  "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(achieved / HBM_PEAK_GBS, 5),
                                  "traffic": pmc_traffic("r01_pmc_msm20.csv", "msm_accumulate_kernel") if args.log_gates == 20 else None,

@@ -187,6 +187,16 @@ int zkgpu_prover_key_commitments(zkgpu_ctx *ctx, uint64_t *out_xy, uint8_t *out_
 int zkgpu_prover_key_poly(zkgpu_ctx *ctx, int which, uint64_t *out);
 int zkgpu_prover_key_eval8n(zkgpu_ctx *ctx, int which, uint64_t *out);
 
+/* Multi-GPU proving, one context per GPU: this context's SRS holds the points [shard_base, shard_base + its point
+ * count) of an SRS of total_points points.  Every commitment of zkgpu_prover_key_load and zkgpu_prove then sums this
+ * context's range only and calls `exchange(user, mine, m, all)`, which must all-gather the m partial sums (18 limbs
+ * each) of every rank into all[rank][m][18] and return 0; the sums are added in rank order, so all ranks obtain the
+ * same proof.  Everything else (transforms, quotient) runs replicated.  exchange == NULL switches sharding off.
+ * No counterpart in the reference, which proves on one host. */
+typedef int (*zkgpu_exchange_fn)(void *user, const uint64_t *mine, size_t m, uint64_t *all);
+int zkgpu_prover_set_sharding(zkgpu_ctx *ctx, uint64_t shard_base, uint64_t total_points, uint32_t world,
+                              zkgpu_exchange_fn exchange, void *user);
+
 /* build_quotient_polynomial (plonk/src/proof_system/quotient_poly.rs:15-100).  `polys` packs the coefficient
  * vectors z, a, b, c, d, pi back to back with lens[6]; challenges7 = alpha beta gamma range logic fixed_base
  * var_base.  t_out receives 8n coefficients of which *t_len remain after dropping leading zeros. */

@@ -83,6 +83,9 @@ extern "C" {
                                           out_xyz: *mut u64, violations: *mut u64) -> c_int;
     pub fn zkgpu_g1_compress(xy: *const u64, infinity: u8, out: *mut u8) -> c_int;
 
+    pub fn zkgpu_prover_set_sharding(ctx: *mut zkgpu_ctx, shard_base: u64, total_points: u64, world: u32,
+                                     exchange: Option<unsafe extern "C" fn(*mut c_void, *const u64, usize, *mut u64) -> c_int>,
+                                     user: *mut c_void) -> c_int;
     pub fn zkgpu_prover_key_load(ctx: *mut zkgpu_ctx, n: u32, constraints: u64, selector_evals: *const u64,
                                  label: *const c_char, label_len: usize, pi_indexes: *const u64, n_pi: usize) -> c_int;
     pub fn zkgpu_prover_key_commitments(ctx: *mut zkgpu_ctx, out_xy: *mut u64, out_infinity: *mut u8) -> c_int;

@@ -71,6 +71,7 @@ SIGNATURES = {
     "zkgpu_field_mul_selfcheck": (C.c_int, [C.c_int, _P, _P, C.c_size_t, _P]),
     "zkgpu_g1_bucket_selfcheck": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P]),
     "zkgpu_g1_bucket_selfcheck_tree": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P]),
+    "zkgpu_prover_set_sharding": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, _P, _P]),
     "zkgpu_prover_key_load": (C.c_int, [_P, C.c_uint32, C.c_uint64, _P, C.c_char_p, C.c_size_t, _P, C.c_size_t]),
     "zkgpu_prover_key_commitments": (C.c_int, [_P, _P, _P]),
     "zkgpu_prover_key_poly": (C.c_int, [_P, C.c_int, _P]),

@@ -493,6 +493,11 @@ int zkgpu_prover_key_load(zkgpu_ctx *ctx, uint32_t n, uint64_t constraints, cons
     });
 }
 
+int zkgpu_prover_set_sharding(zkgpu_ctx *ctx, uint64_t shard_base, uint64_t total_points, uint32_t world,
+                              zkgpu_exchange_fn exchange, void *user) {
+    return guarded(ctx, [&] { ctx->prover->set_sharding(shard_base, total_points, world, exchange, user); });
+}
+
 int zkgpu_prover_key_commitments(zkgpu_ctx *ctx, uint64_t *out_xy, uint8_t *out_infinity) {
     return guarded(ctx, [&] {
         ZK_REQUIRE(ctx->prover->loaded(), ZKGPU_ERR_NOT_LOADED, "no prover key loaded");

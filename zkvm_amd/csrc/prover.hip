@@ -87,31 +87,68 @@ size_t Prover::device_bytes() const { return polys_.cap + evals_.cap + sigma_.ca
 
 const Fr *Prover::key_eval8n(int k) const { return reinterpret_cast<const Fr *>(evals_.p) + (size_t)k * 8 * n_; }
 
-int Prover::commit_dev(const Fr *coeffs, uint64_t len, AffineOut &out) {
-    const uint64_t eff = poly_.length_without_leading_zeros(coeffs, len);
-    const uint64_t degree = eff ? eff - 1 : 0;  // Polynomial::degree (polynomial.rs:79-93)
-    if (degree == 0) return ZKGPU_ERR_DEGREE_ZERO;
-    if (degree > msm_.n_points() - 1) return ZKGPU_ERR_DEGREE_LARGE;
-    out = to_affine(msm_.msm(coeffs, eff, 0));
-    return 0;
-}
+int Prover::commit_dev(const Fr *coeffs, uint64_t len, AffineOut &out) { return commit_many(1, &coeffs, &len, &out); }
 
 // Several commitments over the same SRS in one batched MSM.  The reference commits one polynomial after the other
 // and returns the first error (prover.rs:262-265, 344-347): the degree checks run in that order before any work.
+// With sharding set, this context holds the points [shard_base_, shard_base_ + n_local) of an SRS of total_points_
+// points: it sums its own range of every polynomial, the partial sums of all ranks are exchanged through the
+// caller's function and added in rank order, so every rank obtains the same commitments.
 int Prover::commit_many(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, AffineOut *out) {
     uint64_t eff[MsmEngine::MAX_BATCH];
-    size_t eff_sz[MsmEngine::MAX_BATCH];
     poly_.lengths_without_leading_zeros(m, coeffs, lens, eff);
+    const uint64_t total_points = exchange_ ? total_points_ : msm_.n_points();
     for (uint32_t j = 0; j < m; j++) {
         const uint64_t degree = eff[j] ? eff[j] - 1 : 0;
         if (degree == 0) return ZKGPU_ERR_DEGREE_ZERO;
-        if (degree > msm_.n_points() - 1) return ZKGPU_ERR_DEGREE_LARGE;
-        eff_sz[j] = (size_t)eff[j];
+        if (degree > total_points - 1) return ZKGPU_ERR_DEGREE_LARGE;
     }
+    // this context's share of every sum
+    const uint64_t lo = exchange_ ? shard_base_ : 0, local_points = msm_.n_points();
+    const Fr *ptr[MsmEngine::MAX_BATCH];
+    size_t cnt[MsmEngine::MAX_BATCH];
+    uint32_t slot[MsmEngine::MAX_BATCH], k = 0;
     G1Proj sums[MsmEngine::MAX_BATCH];
-    msm_.msm_batch(m, coeffs, eff_sz, 0, sums);
+    for (uint32_t j = 0; j < m; j++) {
+        sums[j] = G1Proj::identity();
+        uint64_t hi = eff[j] < lo + local_points ? eff[j] : lo + local_points;
+        if (hi <= lo) continue;
+        ptr[k] = coeffs[j] + lo;
+        cnt[k] = (size_t)(hi - lo);
+        slot[k++] = j;
+    }
+    if (k) {
+        G1Proj part[MsmEngine::MAX_BATCH];
+        msm_.msm_batch(k, ptr, cnt, 0, part);
+        for (uint32_t i = 0; i < k; i++) sums[slot[i]] = part[i];
+    }
+    if (exchange_) {
+        std::vector<uint64_t> mine((size_t)m * 18), all((size_t)world_ * m * 18);
+        for (uint32_t j = 0; j < m; j++) memcpy(mine.data() + 18 * j, &sums[j], sizeof(G1Proj));
+        const int rc = exchange_(exchange_user_, mine.data(), m, all.data());
+        ZK_REQUIRE(rc == 0, ZKGPU_ERR_INTERNAL, "commit: the partial-sum exchange failed");
+        for (uint32_t j = 0; j < m; j++) {
+            G1Proj total = G1Proj::identity();
+            for (uint32_t r = 0; r < world_; r++) {
+                G1Proj p;
+                memcpy(&p, all.data() + ((size_t)r * m + j) * 18, sizeof p);
+                total = g1_add(total, p);
+            }
+            sums[j] = total;
+        }
+    }
     for (uint32_t j = 0; j < m; j++) out[j] = to_affine(sums[j]);
     return 0;
+}
+
+void Prover::set_sharding(uint64_t shard_base, uint64_t total_points, uint32_t world, ExchangeFn fn, void *user) {
+    ZK_REQUIRE(fn == nullptr || (world >= 1 && shard_base + msm_.n_points() <= total_points), ZKGPU_ERR_INVALID_ARG,
+               "prover_set_sharding: this context's range lies outside the SRS");
+    exchange_ = fn;
+    exchange_user_ = user;
+    shard_base_ = shard_base;
+    total_points_ = total_points;
+    world_ = fn ? world : 1;
 }
 
 void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector_evals_host, const std::string &label,

@@ -39,6 +39,10 @@ class Prover {
     // composer/permutation.rs:111-141).  Requires the SRS to be loaded.
     void load_key(uint32_t n, uint64_t constraints, const uint64_t *selector_evals_host, const std::string &label,
                   const uint64_t *pi_indexes, size_t n_pi);
+    // Point-range sharding of every commitment over several contexts (one per GPU): `fn(user, mine, m, all)` must
+    // all-gather m partial sums of 18 limbs each into all[rank][m][18]; nullptr switches sharding off.
+    typedef int (*ExchangeFn)(void *user, const uint64_t *mine, size_t m, uint64_t *all);
+    void set_sharding(uint64_t shard_base, uint64_t total_points, uint32_t world, ExchangeFn fn, void *user);
     bool loaded() const { return n_ != 0; }
     uint32_t n() const { return n_; }
     const AffineOut *selector_comms() const { return sel_comms_; }
@@ -68,6 +72,10 @@ class Prover {
     NttEngine &ntt_;
     MsmEngine &msm_;
     PolyEngine &poly_;
+    ExchangeFn exchange_ = nullptr;
+    void *exchange_user_ = nullptr;
+    uint64_t shard_base_ = 0, total_points_ = 0;
+    uint32_t world_ = 1;
     uint32_t n_ = 0, log_n_ = 0;
     uint64_t constraints_ = 0;
     std::string label_;

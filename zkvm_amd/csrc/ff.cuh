@@ -4,9 +4,8 @@
 // buffers cross the C boundary without conversion.  Every result is fully reduced to [0, p), as the
 // reference's are (scalar.rs:524,577; fp.rs:332-348) — results are compared as raw limbs.
 //
-// The multiplier is a product-scanning (column-wise) Montgomery multiplication: each column accumulates
-// a_i*b_j and m_i*p_j partial products into a 96-bit accumulator with v_mad_u64_u32 (+ carry word), which
-// costs one multiply-add and one add-with-carry per partial product and keeps all limbs in VGPRs.
+// Additions and subtractions work on the 32-bit words with the hardware carry; the Montgomery product unpacks
+// to unsaturated limbs (see Fp_::mul) so that its columns need no carry instructions.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -15,40 +14,7 @@
 
 namespace zk {
 
-// 96-bit column accumulator.
-struct Acc96 {
-    uint64_t lh;  // low 64 bits
-    uint32_t ex;  // bits 64..95
-};
-
-FF_HD void acc_mac(Acc96 &c, uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-        : "+v"(c.lh), "+v"(c.ex)
-        : "v"(a), "v"(b)
-        : "vcc");
-#else
-    uint64_t p = (uint64_t)a * b;
-    c.lh += p;
-    c.ex += (c.lh < p);
-#endif
-}
-// First product of a column whose accumulator is known to be < 2^33: cannot overflow 64 bits.
-FF_HD void acc_mac_nocarry(Acc96 &c, uint32_t a, uint32_t b) { c.lh += (uint64_t)a * b; }
-
-FF_HD void acc_add32(Acc96 &c, uint32_t v) {
-    uint64_t t = c.lh + v;
-    c.ex += (t < c.lh);
-    c.lh = t;
-}
-FF_HD uint32_t acc_shift(Acc96 &c) {
-    uint32_t lo = (uint32_t)c.lh;
-    c.lh = (c.lh >> 32) | ((uint64_t)c.ex << 32);
-    c.ex = 0;
-    return lo;
-}
-
-// P supplies: static constexpr int N; MOD[N]; R[N] (= one); R2[N]; INV32 (= -p^-1 mod 2^32)
+// P supplies: N, mod(i), one(i) (= R mod p), r2(i), and the unsaturated form UL, UN, USH, UINV, umod(i)
 template <class P>
 struct Fp_ {
     static constexpr int N = P::N;
@@ -290,7 +256,6 @@ struct Fp_ {
 // ---- BLS12-381 scalar field (coset-bls12_381/src/scalar.rs:80-85,156-170) --------------------------------
 struct FrParams {
     static constexpr int N = 8;
-    static constexpr uint32_t INV32 = 0xffffffffu;
     // unsaturated form used inside mul: 9 limbs of 29 bits, radix 2^261 = 2^256 * 2^5
     static constexpr int UL = 29, UN = 9, USH = 5;
     static constexpr uint32_t UINV = 0x1fffffffu;   // -r^-1 mod 2^29
@@ -318,7 +283,6 @@ struct FrParams {
 // ---- BLS12-381 base field (coset-bls12_381/src/fp.rs:77-104) -----------------------------------------------
 struct FqParams {
     static constexpr int N = 12;
-    static constexpr uint32_t INV32 = 0xfffcfffdu;
     // unsaturated form used inside mul: 14 limbs of 28 bits, radix 2^392 = 2^384 * 2^8
     static constexpr int UL = 28, UN = 14, USH = 8;
     static constexpr uint32_t UINV = 0x0ffcfffdu;   // -p^-1 mod 2^28

@@ -151,15 +151,4 @@ FF_HD void g1_to_affine(const G1Proj &p, Fq &x, Fq &y, bool &infinity) {
     infinity = false;
 }
 
-// k * p for a small unsigned k (double-and-add from the top bit)
-FF_HD G1Proj g1_mul_small(const G1Proj &p, uint32_t k) {
-    G1Proj acc = G1Proj::identity();
-    if (k == 0) return acc;
-    for (int b = 31 - __builtin_clz(k); b >= 0; b--) {
-        acc = g1_double(acc);
-        if ((k >> b) & 1) acc = g1_add(acc, p);
-    }
-    return acc;
-}
-
 }  // namespace zk

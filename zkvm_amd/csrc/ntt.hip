@@ -73,17 +73,6 @@ struct NttPassArgs {
     uint32_t unit_last;  // 1 when the table entry of the h = 1 stage is 1 (plain tables): skip that product
 };
 
-__device__ __forceinline__ Fr lds_get(const uint4 *lo, const uint4 *hi, uint32_t e) {
-    Fr r;
-    uint4 a = lo[e], b = hi[e];
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    return r;
-}
-__device__ __forceinline__ void lds_put(uint4 *lo, uint4 *hi, uint32_t e, const Fr &r) {
-    lo[e] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-    hi[e] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
-}
 __device__ __forceinline__ Fr gload(const Fr *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
     uint4 a = q[0], b = q[1];

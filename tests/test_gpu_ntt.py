@@ -22,8 +22,11 @@ def edge_vectors(n):
     one = M.fr_to_mont(1)
     delta = np.zeros((n, 4), np.uint64)
     delta[0] = one
+    raw_max = M.int_to_limbs(M.R_MOD - 1, 4)          # the largest canonical limb pattern: sums grow fastest
+    alt = np.tile(raw_max, (n, 1))
+    alt[1::2] = 0                                      # max / 0 alternating: differences stay at the maximum
     return {"zero": np.zeros((n, 4), np.uint64), "delta": delta, "ones": np.tile(one, (n, 1)),
-            "r_minus_1": np.tile(p_minus_1, (n, 1))}
+            "r_minus_1": np.tile(p_minus_1, (n, 1)), "raw_max": np.tile(raw_max, (n, 1)), "max_zero": alt}
 
 
 @pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 10, 12, 13, 14, 16])
@@ -36,7 +39,7 @@ def test_ntt_matches_oracle(ctx, orc, log_n):
         assert np.array_equal(got, want), (mode, log_n)
 
 
-@pytest.mark.parametrize("log_n", [4, 13])
+@pytest.mark.parametrize("log_n", [4, 9, 13, 18])
 def test_ntt_edge_vectors(ctx, orc, log_n):
     n = 1 << log_n
     for name, x in edge_vectors(n).items():

@@ -703,20 +703,35 @@ size_t MsmEngine::device_bytes() const {
            tasks_.cap + partials_.cap + misc_.cap + seg_.cap + group_sums_.cap + order_.cap + digits_.cap + table28_.cap + range_cnt_.cap + mid_.cap;
 }
 
-// Window width for a table of n points: minimises n * K * 11 products of accumulation plus ~30 products per
-// bucket of reduction; K = floor(255 / c) + 1 signed digits always cover a 255-bit scalar.  All levels share
-// one bucket set, so a short top window (255 - (K-1) c bits) piles its n digits onto few buckets, which then
-// go through the slower oversized-bucket path: such widths are charged for it.
+// Window width for a table of n points, from a time model (milliseconds) fitted to MI355X measurements
+// (tools/msm_window_sweep.py).  K = floor(255 / c) + 1 signed digits always cover a 255-bit scalar.
+//   accumulate: one thread per bucket, so it is the larger of the throughput term (10 products per addition at the
+//               achieved ~61 G products/s) and the depth term: the deepest bucket's additions at ~16 us each — few
+//               buckets mean long dependent chains on a mostly idle chip;
+//   reduce:     ~0.3 ms of latency plus the work of 2 additions per bucket;
+//   sort:       ~27 ps per (scalar, digit) pair;
+//   a short top window (255 - (K-1) c bits) piles its n digits onto 2^top buckets, all levels sharing one bucket
+//   set: they either deepen the deepest bucket or go through the oversized-bucket path.
 uint32_t MsmEngine::choose_window(size_t n) {
-    uint32_t best = 4;
-    double best_cost = 1e300;
+    uint32_t best = 13;
+    double best_ms = 1e300;
     for (uint32_t c = 4; c <= 22; c++) {
         const uint32_t K = 255 / c + 1, top_bits = 255 - (K - 1) * c;
-        const double mean = (double)n * K / (double)(1u << (c - 1));
-        double cost = (double)n * K * 11.0 + (double)(1u << (c - 1)) * 30.0;
-        if (top_bits < c - 1 && (double)n / (double)(1u << top_bits) > 2.0 * mean + BIG_BUCKET) cost += (double)n * 11.0 * 4.0;
-        if (cost < best_cost) {
-            best_cost = cost;
+        const double B = (double)(1u << (c - 1)), items = (double)n * K, mean = items / B;
+        const double log_b = (double)(c - 1);
+        double reduce = 0.29 + 0.0125 * ((log_b < 16 ? log_b : 16) > 7 ? (log_b < 16 ? log_b : 16) - 7 : 0);
+        if (B > 65536.0) reduce += (B - 65536.0) * 0.5e-6;
+        const double sort = 0.06 + items * 27e-9;
+        double oversized = 0, deepest = mean;
+        if (top_bits < c - 1) {
+            const double extra = (double)n / (double)(1u << top_bits);
+            if (extra > 4 * mean + BIG_BUCKET) oversized = 0.35 + (double)n * 10 / 30e9 * 1e3;
+            else deepest = mean + extra;
+        }
+        const double depth = deepest * 0.016, throughput = items * 10 / 61e9 * 1e3;
+        const double ms = (depth > throughput ? depth : throughput) + 0.05 + reduce + sort + oversized;
+        if (ms < best_ms) {
+            best_ms = ms;
             best = c;
         }
     }

@@ -136,6 +136,20 @@ def test_msm_2_16_device_scalars_and_sharding(ctx, orc):
     assert inf == want_inf and np.array_equal(xy, want_xy)
 
 
+def test_msm_repeated_scalars_default_window(ctx, orc):
+    """Runs of equal scalars give buckets from a few entries to thousands on every level: below the oversize
+    threshold they stay with one thread, above it they are split into workgroup tasks (one and several chunks)."""
+    n = 1 << 14
+    pts, _ = orc.g1_multiples_of_generator(5, n)
+    sc = M.random_fr_mont(n, 77)
+    pos = 0
+    for run in (3, 40, 63, 64, 65, 66, 100, 255, 256, 257, 700, 4096, 4500):
+        sc[pos:pos + run] = sc[pos]
+        pos += run
+    assert pos < n
+    check(ctx, orc, pts, sc)
+
+
 @pytest.mark.parametrize("window_bits,segment_bits", [(4, 1), (5, 3), (9, 2), (13, 4), (16, 3), (18, 6), (21, 5), (22, 4)])
 def test_msm_window_and_segment_widths(ctx, orc, window_bits, segment_bits):
     """The table of window multiples and the bucket reduction are exact for every window width (1 to 64 levels,

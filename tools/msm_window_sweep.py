@@ -1,5 +1,6 @@
 """Phase times of one MSM over window widths, for tuning MsmEngine::choose_window:
-   python tools/msm_window_sweep.py LOG_N c1 c2 ..."""
+   python tools/msm_window_sweep.py LOG_N c1 c2 ...     (c = 0: the engine's own choice)
+   DUP=k in the environment makes the first k scalars equal (k-entry buckets on every level)."""
 import os
 import sys
 
@@ -17,7 +18,11 @@ def main():
     n = 1 << log_n
     device = torch.device("cuda", 0)
     ctx = zkvm_amd.Context(0)
-    sc = bench.to_dev(bench.random_fr(n, 3), device)
+    host = bench.random_fr(n, 3)
+    dup = int(os.environ.get("DUP", "0"))
+    if dup:
+        host[:dup] = host[0]
+    sc = bench.to_dev(host, device)
     for c in cs:
         ctx.msm_set_params(c, 0)
         ctx.srs_setup(circuits.seeded_tau(), circuits.g1_generator_limbs(), n)

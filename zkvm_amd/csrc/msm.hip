@@ -23,6 +23,7 @@
 // commitment compared by the tests, is the same group element.
 #include "msm.hpp"
 #include "fq28.cuh"
+#include <cmath>
 #include <cstring>
 
 namespace zk {
@@ -396,7 +397,7 @@ static const uint32_t N_CLASSES = BIG_BUCKET + 1;
 
 template <int PASS>
 __global__ void __launch_bounds__(1024) msm_schedule_kernel(const uint32_t *counts, uint32_t nb, uint32_t shift,
-                                                            uint32_t *class_cursor, uint32_t *order) {
+                                                            uint32_t big, uint32_t *class_cursor, uint32_t *order) {
     __shared__ uint32_t hist[N_CLASSES];
     __shared__ uint32_t base[N_CLASSES];
     for (uint32_t t = threadIdx.x; t < N_CLASSES; t += blockDim.x) hist[t] = 0;
@@ -405,7 +406,7 @@ __global__ void __launch_bounds__(1024) msm_schedule_kernel(const uint32_t *coun
     uint32_t cls = 0xffffffffu, rank = 0;
     if (i < nb) {
         uint32_t cnt = counts[i];
-        if (cnt <= (BIG_BUCKET << shift)) {
+        if (cnt <= big) {
             cls = BIG_BUCKET - (cnt >> shift);
             rank = atomicAdd(&hist[cls], 1u);
         }
@@ -832,10 +833,19 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
         if ((uint64_t)lens[j] * K > max_items) max_items = (uint64_t)lens[j] * K;
     }
     ZK_REQUIRE(total_items < (1ull << 32) - 2048, ZKGPU_ERR_INVALID_ARG, "msm: too many (point, window) pairs for 32-bit offsets");
-    uint32_t class_shift = 0;   // oversize threshold = 256 << shift >= four times the mean bucket size
-    while (((uint64_t)BIG_BUCKET << class_shift) < 4 * (max_items >> log_B) && class_shift < 12) class_shift++;
-    const uint32_t big = BIG_BUCKET << class_shift;
-    const uint32_t max_tasks = (uint32_t)(total_items / big + m);
+    // A bucket is summed by one thread unless it is oversized: beyond expect + 8 sqrt(expect) + 16 entries, where
+    // expect is the size of the fullest ordinary buckets (mean + the share of a short top window); random digits
+    // stay below that.  The chain of a longer bucket on one thread would be the tail of the accumulate launch.
+    const uint32_t top_bits = 255 - (K - 1) * c;
+    uint64_t expect = max_items >> log_B;
+    if (top_bits < log_B) expect += (max_items / K) >> top_bits;
+    uint64_t big64 = expect + 16 + (uint64_t)(8.0 * std::sqrt((double)expect));
+    uint32_t class_shift = 0;   // size classes are count >> shift, shift the smallest with big <= 256 << shift
+    while (((uint64_t)BIG_BUCKET << class_shift) < big64 && class_shift < 12) class_shift++;
+    if (big64 > ((uint64_t)BIG_BUCKET << class_shift)) big64 = (uint64_t)BIG_BUCKET << class_shift;
+    const uint32_t big = (uint32_t)big64;
+    // every oversized bucket gives ceil(count / BIG_CHUNK) tasks: at most one per `big` entries plus one per chunk
+    const uint32_t max_tasks = (uint32_t)(total_items / big + total_items / BIG_CHUNK + m);
     const uint32_t n_scan_blocks = ceil_div(nb, SCAN_ITEMS);
     const uint32_t log_seg = log_B < seg_bits_ ? log_B : seg_bits_;
     const uint32_t segs_per_sum = 1u << (log_B - log_seg);
@@ -969,9 +979,9 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
         uint32_t *cc = class_cursor + (size_t)j * (N_CLASSES + 1);
         uint32_t *ord = order + (size_t)j * B;
         const uint32_t *cnt = counts_.as<uint32_t>() + (size_t)j * B;
-        hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024)), dim3(1024), 0, stream_, cnt, B, class_shift, cc, ord);
+        hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024)), dim3(1024), 0, stream_, cnt, B, class_shift, big, cc, ord);
         hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(1), dim3(64), 0, stream_, cc);
-        hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024)), dim3(1024), 0, stream_, cnt, B, class_shift, cc, ord);
+        hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024)), dim3(1024), 0, stream_, cnt, B, class_shift, big, cc, ord);
     }
     if (profile_) ZK_HIP(hipEventRecord(profile_[1], stream_));
     for (uint32_t j = 0; j < m; j++) {

@@ -255,7 +255,9 @@ def run_msm(args, rank, world, local, device):
         products = 10.0 * shard * windows / (acc_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "msm_accumulate_kernel (this rank's %d points)" % shard,
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "frac": round(achieved / HBM_PEAK_GBS, 5),
+                           "traffic": pmc_traffic("r01_pmc_msm22.csv", "msm_accumulate_kernel") if shard == 1 << 22 else None,
+                           "traffic_note": "profiles/r01_pmc_msm22.csv: the same kernel on 2^22 points",
                            "avg_launch_ms": round(acc_ms, 4), "algorithmic_bytes_per_launch": int(alg),
                            "valu": {"unit": "G Fq products/s", "achieved": round(products, 1), "peak": FQ28_MUL_PEAK_G,
                                     "frac": round(products / FQ28_MUL_PEAK_G, 3)},

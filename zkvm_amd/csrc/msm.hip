@@ -65,8 +65,15 @@ __device__ __forceinline__ G1Affine gload_affine(const G1Affine *p) {
     r.y = gload_fq(q + 3);
     return r;
 }
-__device__ __forceinline__ G1Affine28 gload_affine28(const G1Affine28 *p) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+// Table entries sit on a 128-byte pitch (112 bytes of limbs + 16 of padding) so that the random read of one entry
+// touches a single 128-byte line instead of two.
+static const uint32_t TABLE_PITCH = 128;
+struct alignas(128) G1Table28 {
+    uint4 q[8];
+};
+static_assert(sizeof(G1Table28) == TABLE_PITCH, "table pitch");
+__device__ __forceinline__ G1Affine28 gload_affine28(const G1Table28 *p) {
+    const uint4 *q = p->q;
     G1Affine28 r;
     uint32_t w[28];
 #pragma unroll
@@ -81,8 +88,8 @@ __device__ __forceinline__ G1Affine28 gload_affine28(const G1Affine28 *p) {
     }
     return r;
 }
-__device__ __forceinline__ void gstore_affine28(G1Affine28 *p, const G1Affine28 &a) {
-    uint4 *q = reinterpret_cast<uint4 *>(p);
+__device__ __forceinline__ void gstore_affine28(G1Table28 *p, const G1Affine28 &a) {
+    uint4 *q = p->q;
     uint32_t w[28];
 #pragma unroll
     for (int k = 0; k < 14; k++) {
@@ -431,7 +438,7 @@ __global__ void msm_schedule_scan_kernel(uint32_t *class_cursor) {
 }
 
 // ---- bucket accumulation ----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) msm_accumulate_kernel(const G1Affine28 *points, const uint32_t *sorted,
+__global__ void __launch_bounds__(256) msm_accumulate_kernel(const G1Table28 *points, const uint32_t *sorted,
                                                              const uint32_t *offsets, const uint32_t *counts,
                                                              const uint32_t *order, const uint32_t *n_scheduled,
                                                              G1Xyzz *buckets) {
@@ -484,7 +491,7 @@ __device__ __forceinline__ G1Xyzz block_tree_sum(uint32_t *sh, G1Xyzz acc, uint3
     return acc;
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_big_partial_kernel(const G1Affine28 *points, const uint32_t *sorted,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_big_partial_kernel(const G1Table28 *points, const uint32_t *sorted,
                                                               const MsmTask *tasks, const uint32_t *task_count,
                                                               uint32_t max_tasks, G1Xyzz *partials) {
     __shared__ uint32_t sh[TREE_LDS_WORDS];
@@ -597,7 +604,7 @@ __device__ __forceinline__ void gstore_affine(G1Affine *p, const Fq &x, const Fq
 // Thread t extends point first + t: level w holds 2^(c w) * P in affine form.  The projective multiples are
 // written unnormalised first; their Z coordinates and running products go to scratch so that one inversion per
 // point converts all levels (Montgomery's trick along the levels).
-__global__ void __launch_bounds__(256) msm_table_kernel(G1Affine *table, G1Affine28 *table28, uint32_t stride, uint32_t first,
+__global__ void __launch_bounds__(256) msm_table_kernel(G1Affine *table, G1Table28 *table28, uint32_t stride, uint32_t first,
                                                         uint32_t count, uint32_t c, uint32_t K, Fq *z_scratch,
                                                         Fq *prefix_scratch) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -745,14 +752,14 @@ void MsmEngine::build_table(size_t n) {
     ZK_REQUIRE((uint64_t)n * K_ < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "srs_load: table of window multiples exceeds 2^31 entries");
     n_points_ = n;
     if (n == 0) return;
-    table28_.reserve((size_t)K_ * n * sizeof(G1Affine28));
+    table28_.reserve((size_t)K_ * n * sizeof(G1Table28));
     const uint32_t chunk = n < (1u << 18) ? (uint32_t)n : (1u << 18);
     misc_.reserve((size_t)2 * (K_ - 1) * chunk * sizeof(Fq));
     Fq *z_scratch = misc_.as<Fq>(), *prefix_scratch = z_scratch + (size_t)(K_ - 1) * chunk;
     for (size_t first = 0; first < n; first += chunk) {
         uint32_t count = (uint32_t)(n - first < chunk ? n - first : chunk);
         hipLaunchKernelGGL(msm_table_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, stream_, points_.as<G1Affine>(),
-                           table28_.as<G1Affine28>(), (uint32_t)n, (uint32_t)first, count, c_, K_, z_scratch, prefix_scratch);
+                           table28_.as<G1Table28>(), (uint32_t)n, (uint32_t)first, count, c_, K_, z_scratch, prefix_scratch);
     }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(stream_));
@@ -901,7 +908,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     const uint32_t n_segments = m * segs_per_sum;
     G1Xyzz *t_seg = seg_.as<G1Xyzz>(), *w_seg = t_seg + n_segments;
 
-    const G1Affine28 *table = table28_.as<G1Affine28>();
+    const G1Table28 *table = table28_.as<G1Table28>();
     ZK_HIP(hipMemsetAsync(task_count, 0, 4, stream_));
     ZK_HIP(hipMemsetAsync(class_cursor, 0, (size_t)m * (N_CLASSES + 1) * 4, stream_));
 

@@ -570,4 +570,49 @@ static inline int prove(const Prover &pr, const FrVec wires[4], const FrVec &pub
     return 0;
 }
 
+// The transcript half of verification: Verifier::verify (compiler/verifier.rs:187-217: the key-seeded transcript, then
+// every public input under "pi") followed by Proof::verify's replay of the proof (proof_system/proof.rs:186-255).
+// Returns beta gamma alpha range logic fixed var z v v_w u.
+static inline std::vector<Fr> verifier_challenges(const std::string &label, const G1Affine comms[N_SEL], uint64_t constraints,
+                                                  const FrVec &public_inputs, const Proof &proof) {
+    Transcript t = transcript_base(label, comms, constraints);
+    for (auto &pi : public_inputs) t.append_scalar("pi", pi);
+    t.append_commitment("a_comm", proof.a_comm);
+    t.append_commitment("b_comm", proof.b_comm);
+    t.append_commitment("c_comm", proof.c_comm);
+    t.append_commitment("d_comm", proof.d_comm);
+    std::vector<Fr> out;
+    out.push_back(t.challenge_scalar("beta"));
+    t.append_scalar("beta", out[0]);
+    out.push_back(t.challenge_scalar("gamma"));
+    t.append_commitment("z_comm", proof.z_comm);
+    for (const char *name : {"alpha", "range separation challenge", "logic separation challenge",
+                             "fixed base separation challenge", "variable base separation challenge"})
+        out.push_back(t.challenge_scalar(name));
+    t.append_commitment("t_low_comm", proof.t_low_comm);
+    t.append_commitment("t_mid_comm", proof.t_mid_comm);
+    t.append_commitment("t_high_comm", proof.t_high_comm);
+    t.append_commitment("t_fourth_comm", proof.t_fourth_comm);
+    out.push_back(t.challenge_scalar("z_challenge"));
+    const ProofEvaluations &e = proof.evaluations;
+    const struct {
+        const char *name;
+        const Fr *v;
+    } order[] = {{"a_eval", &e.a_eval},       {"b_eval", &e.b_eval},
+                 {"c_eval", &e.c_eval},       {"d_eval", &e.d_eval},
+                 {"s_sigma_1_eval", &e.s_sigma_1_eval}, {"s_sigma_2_eval", &e.s_sigma_2_eval},
+                 {"s_sigma_3_eval", &e.s_sigma_3_eval}, {"z_eval", &e.z_eval},
+                 {"a_w_eval", &e.a_w_eval},   {"b_w_eval", &e.b_w_eval},
+                 {"d_w_eval", &e.d_w_eval},   {"q_arith_eval", &e.q_arith_eval},
+                 {"q_c_eval", &e.q_c_eval},   {"q_l_eval", &e.q_l_eval},
+                 {"q_r_eval", &e.q_r_eval}};
+    for (auto &o : order) t.append_scalar(o.name, *o.v);
+    out.push_back(t.challenge_scalar("v_challenge"));
+    out.push_back(t.challenge_scalar("v_w_challenge"));
+    t.append_commitment("w_z_chall_comm", proof.w_z_chall_comm);
+    t.append_commitment("w_z_chall_w_comm", proof.w_z_chall_w_comm);
+    out.push_back(t.challenge_scalar("u_challenge"));
+    return out;
+}
+
 }  // namespace oracle

@@ -393,6 +393,18 @@ class Prover:
         return dict(rc=rc, comms=comms, comms_inf=inf, evals=evals, challenges=chal, secs=secs.value)
 
 
+def verifier_challenges(label, sel_xy, sel_inf, constraints, pub_inputs, comms_xy, comms_inf, evals15):
+    """verifier.rs:187-217 + proof.rs:186-255 -> (11, 4): beta gamma alpha range logic fixed var z v v_w u"""
+    pi = _u64(pub_inputs).reshape(-1, 4)
+    out = np.empty((11, 4), np.uint64)
+    lib().orc_verifier_challenges(C.c_char_p(bytes(label)), C.c_size_t(len(label)), _p(_u64(sel_xy).reshape(N_SEL, 12)),
+                                  _p(np.ascontiguousarray(sel_inf, dtype=np.uint8)), C.c_uint64(constraints), _p(pi),
+                                  C.c_size_t(pi.shape[0]), _p(_u64(comms_xy).reshape(11, 12)),
+                                  _p(np.ascontiguousarray(comms_inf, dtype=np.uint8)), _p(_u64(evals15).reshape(15, 4)),
+                                  _p(out))
+    return out
+
+
 def strobe_conformance():
     out = np.empty(64, np.uint8)
     lib().orc_strobe_conformance(_p(out))

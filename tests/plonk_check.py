@@ -1,6 +1,8 @@
-"""The reference verifier's final equation (plonk/src/proof_system/proof.rs:179-404) for arithmetic-only circuits with
-one public input at gate 0, with the pairing replaced by the known trapdoor of a test SRS:
-e(A, [tau]_2) = e(B, [1]_2)  <=>  tau * A = B in G1.  All arithmetic is Python big integers (tests/model.py)."""
+"""The reference verifier (plonk/src/compiler/verifier.rs:187-217, plonk/src/proof_system/proof.rs:179-404) for
+arithmetic-only circuits, in Python big integers (tests/model.py, oracle/pairing.py):
+  verify()          the whole of it: transcript replay, the two pairing points, e(-A, [tau]_2) e(B, [1]_2) == 1;
+  verifier_sides()  the same equation with the pairing replaced by the known trapdoor of a test SRS,
+                    tau * A = B in G1, cheap enough for 2^20-gate proofs in every test run."""
 import model as M
 
 R = M.R_MOD
@@ -11,6 +13,17 @@ EVAL_NAMES = ["a_eval", "b_eval", "c_eval", "d_eval", "a_w_eval", "b_w_eval", "d
               "q_l_eval", "q_r_eval", "s_sigma_1_eval", "s_sigma_2_eval", "s_sigma_3_eval", "z_eval"]
 SEL_NAMES = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic", "q_fixed_group_add",
              "q_variable_group_add", "s_sigma_1", "s_sigma_2", "s_sigma_3", "s_sigma_4"]
+
+
+def opening_key_g2(tau):
+    """(h, [tau] h) of the OpeningKey (kzg10/srs.rs:60-70) for a trapdoor given as an integer; h is the G2 generator
+    taken from the reference's compressed vectors (entry 1 of g2_compressed_valid_test_vectors.dat)."""
+    import os
+    from conftest import GOLDEN
+    from oracle import pairing as Pg
+    data = open(os.path.join(GOLDEN, "g2_compressed_valid_test_vectors.dat"), "rb").read()
+    h = Pg.g2_from_compressed(data[96:192])
+    return h, Pg.g2_mul(h, tau)
 
 
 def _ints(arr):
@@ -24,19 +37,47 @@ def _pt(xy, inf=0):
 
 def verifier_sides(n, proof, sel_xy, sel_inf, public_input0, tau, g_xy, u=None, tamper=0):
     """-> (left, right) of tau * (W_z + u W_zw) = z W_z + u z w W_zw + F - E; equal for a valid proof."""
+    if u is None:
+        u = M.random_fr_ints(1, 1234)[0]       # the verifier's own challenge; the equation must hold for any value
+    a_pt, b_pt = pairing_points(n, proof, sel_xy, sel_inf, {0: public_input0}, g_xy, u, tamper=tamper)
+    return M.ec_mul(a_pt, tau), b_pt
+
+
+def verify(n, constraints, label, proof, sel_xy, sel_inf, public_inputs_mont, pi_indexes, g_xy, h_g2, tau_h_g2, orc):
+    """Verifier::verify: True when the proof is accepted.  public_inputs_mont: (k, 4) Montgomery limbs in the order
+    of pi_indexes; h_g2 / tau_h_g2: the OpeningKey's G2 points (kzg10/key.rs:165-186) as oracle.pairing tuples."""
+    import numpy as np
+    from oracle import pairing as Pg
+    pis = np.asarray(public_inputs_mont, dtype=np.uint64).reshape(-1, 4)
+    if pis.shape[0] != len(pi_indexes):
+        return False                            # Error::InconsistentPublicInputsLen
+    ch = orc.verifier_challenges(label, sel_xy, sel_inf, constraints, pis, proof["comms"], proof["comms_inf"], proof["evals"])
+    replay = dict(proof)
+    replay["challenges"] = ch[:10]              # the verifier trusts its own transcript, not the prover's report
+    u = M.fr_from_mont(ch[10])
+    pi = {idx: v for idx, v in zip(pi_indexes, _ints(pis))}
+    a_pt, b_pt = pairing_points(n, replay, sel_xy, sel_inf, pi, g_xy, u)
+    neg_a = None if a_pt is None else (a_pt[0], (-a_pt[1]) % M.P_MOD)
+    return Pg.pairing_product_is_one([(neg_a, tau_h_g2), (b_pt, h_g2)])
+
+
+def pairing_points(n, proof, sel_xy, sel_inf, public_inputs, g_xy, u, tamper=0):
+    """-> (A, B) with A = W_z + u W_zw and B = z W_z + u z w W_zw + F - E (proof.rs:257-391); the proof is accepted
+    when e(A, [tau]_2) = e(B, [1]_2).  public_inputs: {gate index: value}."""
     G = _pt(g_xy)
     comm = {name: _pt(proof["comms"][i], proof["comms_inf"][i]) for i, name in enumerate(COMM_NAMES)}
     e = dict(zip(EVAL_NAMES, _ints(proof["evals"])))
     beta, gamma, alpha, _, _, _, _, z, v, v_w = _ints(proof["challenges"])
     vk = {name: _pt(sel_xy[i], sel_inf[i]) for i, name in enumerate(SEL_NAMES)}
-    if u is None:
-        u = M.random_fr_ints(1, 1234)[0]       # the verifier's own challenge; the equation must hold for any value
     om = M.domain_root(n)
 
     zh = (pow(z, n, R) - 1) % R
     l1 = zh * pow(n * (z - 1) % R, -1, R) % R
-    # public input polynomial at z (barycentric form, proof.rs:511-561); the only public input sits at gate 0
-    pi_eval = public_input0 * zh * pow(n * (z - 1) % R, -1, R) % R
+    # public input polynomial at z (barycentric form, proof.rs:511-561): sum of pi_j L_j(z)
+    pi_eval = 0
+    for idx, val in public_inputs.items():
+        wj = pow(om, idx, R)
+        pi_eval = (pi_eval + val * wj * zh % R * pow(n * (z - wj) % R, -1, R)) % R
 
     # linearization commitment (proof.rs:408-496, widget/arithmetic/verifierkey.rs:91-117,
     # widget/permutation/verifierkey.rs); the range/logic/ecc selectors of these circuits are identically zero
@@ -73,6 +114,6 @@ def verifier_sides(n, proof, sel_xy, sel_inf, public_input0, tau, g_xy, u=None, 
     E = M.ec_mul(G, e_scalar)
     wz, wzw = comm["w_z_chall_comm"], comm["w_z_chall_w_comm"]
     neg_e = None if E is None else (E[0], (-E[1]) % M.P_MOD)
-    left = M.ec_mul(M.ec_add(wz, M.ec_mul(wzw, u)), tau)
-    right = M.ec_add(M.ec_add(M.ec_mul(wz, z), M.ec_mul(wzw, u * z * om % R)), M.ec_add(F, neg_e))
-    return left, right
+    a_pt = M.ec_add(wz, M.ec_mul(wzw, u))
+    b_pt = M.ec_add(M.ec_add(M.ec_mul(wz, z), M.ec_mul(wzw, u * z * om % R)), M.ec_add(F, neg_e))
+    return a_pt, b_pt

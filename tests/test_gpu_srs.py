@@ -68,6 +68,14 @@ def test_prove_2_20_satisfies_verifier_equation(ctx, orc):
     assert left == right
     left, right = plonk_check.verifier_sides(n, proof, sxy, sinf, pi0, tau_int, gxy, tamper=1)
     assert left != right
+    # and the whole verifier: its own transcript replay, then the pairing check against (h, [tau] h)
+    h, tau_h = plonk_check.opening_key_g2(tau_int)
+    args = (sxy, sinf, c["public_inputs"], c["pi_indexes"], gxy, h, tau_h, orc)
+    assert plonk_check.verify(n, c["constraints"], b"full-size", proof, *args)
+    bad = dict(proof)
+    bad["comms"] = proof["comms"].copy()
+    bad["comms"][9] = proof["comms"][10]
+    assert not plonk_check.verify(n, c["constraints"], b"full-size", bad, *args)
 
 
 def test_srs_range_from_shifted_base(ctx, orc):

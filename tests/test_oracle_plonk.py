@@ -112,3 +112,41 @@ def test_proof_satisfies_verifier_equation_under_trapdoor(orc, n, seed):
     # a tampered evaluation must break the equation
     left, right = plonk_check.verifier_sides(n, proof, sxy, sinf, pi0, tau, srs[0], tamper=1)
     assert left != right
+
+
+@pytest.mark.parametrize("n,seed", [(8, 21), (64, 22)])
+def test_proof_accepted_by_the_pairing_verifier(orc, n, seed):
+    """The whole of Verifier::verify: the verifier's own transcript replay (u included) and the pairing check;
+    the reference's only proof-level test is exactly this acceptance (plonk/tests/composer.rs)."""
+    from zkvm_amd import circuits
+    import plonk_check
+    c, op, tau, srs = _setup(orc, n, seed)
+    proof = op.prove(c["wires"], c["public_inputs"], circuits.random_blinders(seed))
+    assert proof["rc"] == 0
+    sxy, sinf = op.selector_comms()
+    h, tau_h = plonk_check.opening_key_g2(tau)
+    args = (sxy, sinf, c["public_inputs"], c["pi_indexes"], srs[0], h, tau_h, orc)
+    assert plonk_check.verify(n, c["constraints"], b"pin", proof, *args)
+    # the replayed challenges are the prover's
+    ch = orc.verifier_challenges(b"pin", sxy, sinf, c["constraints"], c["public_inputs"], proof["comms"], proof["comms_inf"],
+                                 proof["evals"])
+    assert np.array_equal(ch[:10], proof["challenges"])
+    # every kind of tampering is rejected
+    assert not plonk_check.verify(n, c["constraints"], b"other label", proof, *args)
+    assert not plonk_check.verify(n, c["constraints"] + 1, b"pin", proof, *args)
+    bad = dict(proof)
+    bad["evals"] = proof["evals"].copy()
+    bad["evals"][3] = M.fr_to_mont((M.fr_from_mont(bad["evals"][3]) + 1) % R)
+    assert not plonk_check.verify(n, c["constraints"], b"pin", bad, *args)
+    bad = dict(proof)
+    bad["comms"] = proof["comms"].copy()
+    bad["comms"][[0, 1]] = bad["comms"][[1, 0]]
+    assert not plonk_check.verify(n, c["constraints"], b"pin", bad, *args)
+    wrong_pi = c["public_inputs"].copy()
+    wrong_pi[0] = M.fr_to_mont(12345)
+    assert not plonk_check.verify(n, c["constraints"], b"pin", proof, sxy, sinf, wrong_pi, c["pi_indexes"], srs[0], h, tau_h, orc)
+    assert not plonk_check.verify(n, c["constraints"], b"pin", proof, sxy, sinf, c["public_inputs"][:0], c["pi_indexes"], srs[0],
+                                  h, tau_h, orc)
+    _, other = plonk_check.opening_key_g2(tau + 1)
+    assert not plonk_check.verify(n, c["constraints"], b"pin", proof, sxy, sinf, c["public_inputs"], c["pi_indexes"], srs[0], h,
+                                  other, orc)

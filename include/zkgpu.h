@@ -180,6 +180,19 @@ int zkgpu_g1_compress(const uint64_t xy[12], uint8_t infinity, uint8_t out[48]);
  * the public inputs in ascending order (composer.rs:985-992). */
 int zkgpu_prover_key_load(zkgpu_ctx *ctx, uint32_t n, uint64_t constraints, const uint64_t *selector_evals,
                           const char *label, size_t label_len, const uint64_t *pi_indexes, size_t n_pi);
+/* Prover::try_from_bytes (plonk/src/compiler/prover.rs:137-207): loads a serialized prover — label, ProverKey
+ * (plonk/src/proof_system/widget.rs:374-519: 15 coefficient vectors and their 8n coset evaluations as canonical
+ * little-endian scalars), CommitKey in the raw form (kzg10/key.rs:54-66; it replaces the loaded SRS) and VerifierKey
+ * (widget.rs:102-123: 15 compressed commitments) — into device memory, ready for zkgpu_prove.  The reference keeps
+ * the public-input positions in the circuit (composer.rs:985-992), not in these bytes, so they are passed beside
+ * them.  *n_out receives the key's gate count.  ZKGPU_ERR_INVALID_ARG where the reference returns an Err
+ * (NotEnoughBytes, an invalid point or scalar). */
+int zkgpu_prover_load_bytes(zkgpu_ctx *ctx, const uint8_t *bytes, size_t len, const uint64_t *pi_indexes, size_t n_pi,
+                            uint32_t *n_out);
+/* Prover::to_bytes (plonk/src/compiler/prover.rs:85-134) of the loaded key and SRS, byte for byte the reference's
+ * layout, including ProverKey::serialization_size's rule of budgeting every polynomial at q_m's length
+ * (widget.rs:265-278).  *written receives the size; bytes are written when `out` is not NULL and cap suffices. */
+int zkgpu_prover_to_bytes(zkgpu_ctx *ctx, uint8_t *out, size_t cap, size_t *written);
 /* The 15 commitments of the loaded key (x | y, 12 limbs each) and their infinity flags. */
 int zkgpu_prover_key_commitments(zkgpu_ctx *ctx, uint64_t *out_xy, uint8_t *out_infinity);
 /* Copies of key members for inspection: coefficient vector `which` (n elements), and the 8n coset evaluations

@@ -615,4 +615,113 @@ static inline std::vector<Fr> verifier_challenges(const std::string &label, cons
     return out;
 }
 
+// ---- key serialization (Prover::to_bytes, compiler/prover.rs:85-134) ------------------------------------------
+// A byte sink with the semantics of coset-bytes' `Write for &mut [u8]` (bytes/src/serialize.rs:105-118): a write
+// that does not fit is dropped as a whole, the cursor stays, and the callers ignore the error.
+struct SliceWriter {
+    std::vector<uint8_t> &buf;
+    size_t pos = 0;
+    void write(const uint8_t *d, size_t n) {
+        if (n > buf.size() - pos) return;
+        if (n) memcpy(buf.data() + pos, d, n);
+        pos += n;
+    }
+    void u64le(uint64_t v) {
+        uint8_t b[8];
+        for (int i = 0; i < 8; i++) b[i] = (uint8_t)(v >> (8 * i));
+        write(b, 8);
+    }
+};
+static inline void put_u64be(std::vector<uint8_t> &out, uint64_t v) {
+    for (int i = 7; i >= 0; i--) out.push_back((uint8_t)(v >> (8 * i)));
+}
+// Polynomial::to_var_bytes (fft/polynomial.rs:121-129): coefficients 0..=degree, canonical little-endian
+static inline std::vector<uint8_t> poly_to_var_bytes(const Poly &p) {
+    std::vector<uint8_t> out;
+    const size_t deg = p.degree();
+    for (size_t i = 0; i < p.c.size() && i <= deg; i++) {
+        uint8_t b[32];
+        fr_to_bytes(p.c[i], b);
+        out.insert(out.end(), b, b + 32);
+    }
+    return out;
+}
+// EvaluationDomain::to_bytes (fft/domain.rs:46-66): 8 + 4 + 5 * 32 = 172 bytes
+static const size_t DOMAIN_BYTES = 172;
+static inline void domain_to_bytes(const EvaluationDomain &d, uint8_t out[DOMAIN_BYTES]) {
+    for (int i = 0; i < 8; i++) out[i] = (uint8_t)(d.size >> (8 * i));
+    for (int i = 0; i < 4; i++) out[8 + i] = (uint8_t)(d.log_size_of_group >> (8 * i));
+    const Fr *f[5] = {&d.size_as_field_element, &d.size_inv, &d.group_gen, &d.group_gen_inv, &d.generator_inv};
+    for (int k = 0; k < 5; k++) fr_to_bytes(*f[k], out + 12 + 32 * k);
+}
+// Evaluations::to_var_bytes (fft/evaluations.rs:40-49): the domain, then every value
+static inline std::vector<uint8_t> evals_to_var_bytes(const FrVec &e, const EvaluationDomain &d) {
+    std::vector<uint8_t> out(DOMAIN_BYTES + 32 * e.size());
+    domain_to_bytes(d, out.data());
+    for (size_t i = 0; i < e.size(); i++) fr_to_bytes(e[i], out.data() + DOMAIN_BYTES + 32 * i);
+    return out;
+}
+// Order in which ProverKey::to_var_bytes and VerifierKey::to_bytes walk the selectors (widget.rs:82-97,294-365):
+// q_logic comes before q_range there.
+static const int SERIAL_ORDER[N_SEL] = {Q_M, Q_L, Q_R, Q_O, Q_F, Q_C, Q_ARITH, Q_LOGIC, Q_RANGE, Q_FIXED, Q_VAR, S1, S2, S3, S4};
+
+// ProverKey::to_var_bytes (proof_system/widget.rs:265-372), including its size rule: every polynomial is budgeted
+// at q_m's coefficient count, so the buffer ends in zero padding when others are shorter, and pieces that would
+// overrun it are dropped.
+static inline std::vector<uint8_t> prover_key_to_var_bytes(const ProverKey &pk) {
+    const EvaluationDomain d8(8 * pk.n);
+    const size_t eval_size = pk.eval8n[Q_M].size() * 32 + DOMAIN_BYTES;
+    const size_t size = pk.poly[Q_M].c.size() * 32 * 15 + eval_size * 17 + 8 * 17;
+    std::vector<uint8_t> bytes(size, 0);
+    SliceWriter w{bytes};
+    w.u64le(pk.n);
+    w.u64le(eval_size);
+    for (int k : SERIAL_ORDER) {
+        w.u64le(pk.poly[k].c.size());
+        std::vector<uint8_t> pb = poly_to_var_bytes(pk.poly[k]);
+        w.write(pb.data(), pb.size());
+        std::vector<uint8_t> eb = evals_to_var_bytes(pk.eval8n[k], d8);
+        w.write(eb.data(), eb.size());
+    }
+    std::vector<uint8_t> lb = evals_to_var_bytes(pk.linear_evaluations, d8);
+    w.write(lb.data(), lb.size());
+    std::vector<uint8_t> vb = evals_to_var_bytes(pk.v_h_coset_8n, d8);
+    w.write(vb.data(), vb.size());
+    return bytes;
+}
+// VerifierKey::to_bytes (widget.rs:73-100): n = the constraint count (compiler.rs:211-212), 15 compressed points
+static inline std::vector<uint8_t> verifier_key_to_bytes(uint64_t constraints, const G1Affine comms[N_SEL]) {
+    std::vector<uint8_t> out(8 + 48 * N_SEL);
+    for (int i = 0; i < 8; i++) out[i] = (uint8_t)(constraints >> (8 * i));
+    for (int j = 0; j < N_SEL; j++) g1a_to_compressed(comms[SERIAL_ORDER[j]], out.data() + 8 + 48 * j);
+    return out;
+}
+// CommitKey::to_raw_var_bytes (kzg10/key.rs:38-52)
+static inline std::vector<uint8_t> commit_key_to_raw_var_bytes(const CommitKey &ck) {
+    std::vector<uint8_t> out(8 + 97 * ck.powers_of_g.size());
+    const uint64_t len = ck.powers_of_g.size();
+    for (int i = 0; i < 8; i++) out[i] = (uint8_t)(len >> (8 * i));
+    for (size_t i = 0; i < ck.powers_of_g.size(); i++) g1a_to_raw(ck.powers_of_g[i], out.data() + 8 + 97 * i);
+    return out;
+}
+// Prover::to_bytes (compiler/prover.rs:109-134): six big-endian u64 (label, prover key, commit key and verifier key
+// lengths, size, constraints), then the four pieces
+static inline std::vector<uint8_t> prover_to_bytes(const Prover &pr) {
+    std::vector<uint8_t> pk = prover_key_to_var_bytes(pr.pk), ck = commit_key_to_raw_var_bytes(pr.ck),
+                         vk = verifier_key_to_bytes(pr.constraints, pr.selector_comms);
+    std::vector<uint8_t> out;
+    out.reserve(48 + pr.label.size() + pk.size() + ck.size() + vk.size());
+    put_u64be(out, pr.label.size());
+    put_u64be(out, pk.size());
+    put_u64be(out, ck.size());
+    put_u64be(out, vk.size());
+    put_u64be(out, pr.size);
+    put_u64be(out, pr.constraints);
+    out.insert(out.end(), pr.label.begin(), pr.label.end());
+    out.insert(out.end(), pk.begin(), pk.end());
+    out.insert(out.end(), ck.begin(), ck.end());
+    out.insert(out.end(), vk.begin(), vk.end());
+    return out;
+}
+
 }  // namespace oracle

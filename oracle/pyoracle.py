@@ -50,6 +50,7 @@ def lib():
         _lib.orc_prover_eval8n.restype = C.c_size_t
         _lib.orc_quotient.restype = C.c_size_t
         _lib.orc_linearization.restype = C.c_size_t
+        _lib.orc_prover_to_bytes.restype = C.c_size_t
     return _lib
 
 
@@ -378,6 +379,13 @@ class Prover:
                                     _p(_u64(z_challenge)), _p(_u64(evals15).reshape(15, 4)), _p(pi),
                                     C.c_size_t(pi.shape[0]), _p(out))
         return out[:k].copy()
+
+    def to_bytes(self):
+        """Prover::to_bytes (compiler/prover.rs:109-134) as a numpy uint8 array"""
+        size = lib().orc_prover_to_bytes(self._h, None, C.c_size_t(0))
+        out = np.empty(size, np.uint8)
+        lib().orc_prover_to_bytes(self._h, _p(out), C.c_size_t(size))
+        return out
 
     def prove(self, wires, pub_inputs, blinders14, threads=None):
         w = _u64(wires).reshape(4, self.n, 4)

@@ -88,6 +88,9 @@ extern "C" {
                                      user: *mut c_void) -> c_int;
     pub fn zkgpu_prover_key_load(ctx: *mut zkgpu_ctx, n: u32, constraints: u64, selector_evals: *const u64,
                                  label: *const c_char, label_len: usize, pi_indexes: *const u64, n_pi: usize) -> c_int;
+    pub fn zkgpu_prover_load_bytes(ctx: *mut zkgpu_ctx, bytes: *const u8, len: usize, pi_indexes: *const u64, n_pi: usize,
+                                   n_out: *mut u32) -> c_int;
+    pub fn zkgpu_prover_to_bytes(ctx: *mut zkgpu_ctx, out: *mut u8, cap: usize, written: *mut usize) -> c_int;
     pub fn zkgpu_prover_key_commitments(ctx: *mut zkgpu_ctx, out_xy: *mut u64, out_infinity: *mut u8) -> c_int;
     pub fn zkgpu_prover_key_poly(ctx: *mut zkgpu_ctx, which: c_int, out: *mut u64) -> c_int;
     pub fn zkgpu_prover_key_eval8n(ctx: *mut zkgpu_ctx, which: c_int, out: *mut u64) -> c_int;

@@ -150,3 +150,48 @@ def test_proof_accepted_by_the_pairing_verifier(orc, n, seed):
     _, other = plonk_check.opening_key_g2(tau + 1)
     assert not plonk_check.verify(n, c["constraints"], b"pin", proof, sxy, sinf, c["public_inputs"], c["pi_indexes"], srs[0], h,
                                   other, orc)
+
+
+def test_prover_to_bytes_layout(orc):
+    """Prover::to_bytes (compiler/prover.rs:85-134) read back by an independent Python reader that follows
+    try_from_bytes / ProverKey::from_slice (prover.rs:137-207, widget.rs:374-519)."""
+    n = 16
+    c, op, tau, srs = _setup(orc, n, 31)
+    b = bytes(op.to_bytes())
+    be = lambda o: int.from_bytes(b[o:o + 8], "big")
+    le = lambda buf, o: int.from_bytes(buf[o:o + 8], "little")
+    label_len, pk_len, ck_len, vk_len, size, constraints = (be(8 * i) for i in range(6))
+    assert (label_len, size, constraints) == (3, n, c["constraints"])
+    assert len(b) == 48 + label_len + pk_len + ck_len + vk_len
+    assert b[48:51] == b"pin"
+    pk = b[51:51 + pk_len]
+    ck = b[51 + pk_len:51 + pk_len + ck_len]
+    vk = b[51 + pk_len + ck_len:]
+    assert le(pk, 0) == n and le(pk, 8) == 172 + 8 * n * 32
+    order = [0, 1, 2, 3, 4, 5, 6, 8, 7, 9, 10, 11, 12, 13, 14]      # q_logic before q_range
+    pos = 16
+    scal = lambda buf: M.fr_vec_to_mont([int.from_bytes(buf[i:i + 32], "little") for i in range(0, len(buf), 32)])
+    for k in order:
+        cnt = le(pk, pos)
+        pos += 8
+        want = op.poly(k)
+        assert cnt == want.shape[0]
+        if cnt:
+            assert np.array_equal(scal(pk[pos:pos + 32 * cnt]), want)
+        pos += 32 * cnt
+        assert le(pk, pos) == 8 * n and int.from_bytes(pk[pos + 8:pos + 12], "little") == (8 * n).bit_length() - 1
+        assert int.from_bytes(pk[pos + 12:pos + 44], "little") == 8 * n                     # size_as_field_element
+        assert int.from_bytes(pk[pos + 76:pos + 108], "little") == M.domain_root(8 * n)     # group_gen
+        assert int.from_bytes(pk[pos + 140:pos + 172], "little") == pow(7, -1, R)           # generator_inv
+        assert np.array_equal(scal(pk[pos + 172:pos + 172 + 32 * 8 * n]), op.eval8n(k))
+        pos += 172 + 32 * 8 * n
+    for which in (15, 16):
+        assert np.array_equal(scal(pk[pos + 172:pos + 172 + 32 * 8 * n]), op.eval8n(which))
+        pos += 172 + 32 * 8 * n
+    assert not any(pk[pos:])                               # zero padding of the size budget
+    assert le(ck, 0) == n + 7 and len(ck) == 8 + 97 * (n + 7)
+    assert np.array_equal(np.frombuffer(ck[8:8 + 96], dtype="<u8"), srs[0]) and ck[8 + 96] == 0
+    assert le(vk, 0) == c["constraints"] and len(vk) == 8 + 48 * 15
+    sxy, sinf = op.selector_comms()
+    for j, k in enumerate(order):
+        assert vk[8 + 48 * j:8 + 48 * j + 48] == orc.g1_compress(sxy[k], int(sinf[k]))

@@ -315,6 +315,29 @@ class Prover:
         ctx._check(ctx._lib.zkgpu_prover_key_load(ctx._h, int(n), int(constraints), sel.ctypes.data, bytes(label),
                                                   len(label), idx.ctypes.data if idx.size else None, idx.size))
 
+    @classmethod
+    def try_from_bytes(cls, ctx, data, pi_indexes=()):
+        """Prover::try_from_bytes (plonk/src/compiler/prover.rs:137-207): the serialized prover's keys go straight into
+        device memory; its commit key replaces the SRS loaded in `ctx`."""
+        buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data,
+                                   dtype=np.uint8)
+        idx = np.ascontiguousarray(list(pi_indexes), dtype=np.uint64)
+        n = C.c_uint32(0)
+        ctx._check(ctx._lib.zkgpu_prover_load_bytes(ctx._h, buf.ctypes.data if buf.size else None, buf.size,
+                                                    idx.ctypes.data if idx.size else None, idx.size, C.byref(n)))
+        self = cls.__new__(cls)
+        self.ctx, self.n = ctx, int(n.value)
+        self.constraints = int.from_bytes(bytes(buf[40:48]), "big")
+        return self
+
+    def to_bytes(self):
+        """Prover::to_bytes (plonk/src/compiler/prover.rs:85-134) as a numpy uint8 array."""
+        size = C.c_size_t(0)
+        self.ctx._check(self.ctx._lib.zkgpu_prover_to_bytes(self.ctx._h, None, 0, C.byref(size)))
+        out = np.empty(size.value, dtype=np.uint8)
+        self.ctx._check(self.ctx._lib.zkgpu_prover_to_bytes(self.ctx._h, out.ctypes.data, out.size, C.byref(size)))
+        return out
+
     def selector_commitments(self):
         xy = np.zeros((N_SELECTORS, 12), dtype=np.uint64)
         inf = np.zeros(N_SELECTORS, dtype=np.uint8)

@@ -230,43 +230,15 @@ int zkgpu_srs_export(zkgpu_ctx *ctx, uint64_t *out_xy, uint8_t *out_infinity, si
 }
 
 int zkgpu_srs_load_raw(zkgpu_ctx *ctx, const uint8_t *bytes, size_t len) {
-    return guarded(ctx, [&] {
-        ZK_REQUIRE(bytes != nullptr && len >= 8, ZKGPU_ERR_INVALID_ARG, "srs_load_raw: need at least the 8-byte count");
-        uint64_t count = 0;
-        for (int k = 0; k < 8; k++) count |= (uint64_t)bytes[k] << (8 * k);
-        const uint64_t present = (len - 8) / 97;
-        if (count > present) count = present;   // chunks_exact(..).zip(0..len) stops at the shorter of the two
-        std::vector<uint64_t> xy((size_t)count * 12);
-        std::vector<uint8_t> inf((size_t)count);
-        for (uint64_t i = 0; i < count; i++) {
-            const uint8_t *p = bytes + 8 + 97 * i;
-            for (int w = 0; w < 12; w++) {
-                uint64_t v = 0;
-                for (int k = 0; k < 8; k++) v |= (uint64_t)p[8 * w + k] << (8 * k);
-                xy[12 * i + w] = v;
-            }
-            inf[i] = p[96] ? 1 : 0;
-        }
-        ctx->msm->load_points(xy.data(), inf.data(), (size_t)count);
-    });
+    return guarded(ctx, [&] { ctx->msm->load_points_raw(bytes, len); });
 }
 
 int zkgpu_srs_export_raw(zkgpu_ctx *ctx, uint8_t *out, size_t cap, size_t *written) {
     return guarded(ctx, [&] {
         ZK_REQUIRE(written != nullptr, ZKGPU_ERR_INVALID_ARG, "srs_export_raw: null size output");
-        const size_t n = ctx->msm->n_points();
-        *written = 8 + 97 * n;
+        *written = ctx->msm->raw_size();
         if (out == nullptr || cap < *written) return;
-        std::vector<uint64_t> xy(n * 12);
-        std::vector<uint8_t> inf(n);
-        ctx->msm->export_points(xy.data(), inf.data(), n);
-        for (int k = 0; k < 8; k++) out[k] = (uint8_t)((uint64_t)n >> (8 * k));
-        for (size_t i = 0; i < n; i++) {
-            uint8_t *p = out + 8 + 97 * i;
-            for (int w = 0; w < 12; w++)
-                for (int k = 0; k < 8; k++) p[8 * w + k] = (uint8_t)(xy[12 * i + w] >> (8 * k));
-            p[96] = inf[i];
-        }
+        ctx->msm->export_points_raw(out);
     });
 }
 
@@ -490,6 +462,22 @@ int zkgpu_prover_key_load(zkgpu_ctx *ctx, uint32_t n, uint64_t constraints, cons
         ZK_REQUIRE(label != nullptr || label_len == 0, ZKGPU_ERR_INVALID_ARG, "prover_key_load: null label");
         ZK_REQUIRE(pi_indexes != nullptr || n_pi == 0, ZKGPU_ERR_INVALID_ARG, "prover_key_load: null public input indexes");
         ctx->prover->load_key(n, constraints, selector_evals, std::string(label ? label : "", label_len), pi_indexes, n_pi);
+    });
+}
+
+int zkgpu_prover_load_bytes(zkgpu_ctx *ctx, const uint8_t *bytes, size_t len, const uint64_t *pi_indexes, size_t n_pi,
+                            uint32_t *n_out) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(pi_indexes != nullptr || n_pi == 0, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: null public input indexes");
+        ctx->prover->load_key_bytes(bytes, len, pi_indexes, n_pi);
+        if (n_out) *n_out = ctx->prover->n();
+    });
+}
+
+int zkgpu_prover_to_bytes(zkgpu_ctx *ctx, uint8_t *out, size_t cap, size_t *written) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(written != nullptr, ZKGPU_ERR_INVALID_ARG, "prover_to_bytes: null size output");
+        *written = ctx->prover->to_bytes(out, cap);
     });
 }
 

@@ -53,6 +53,13 @@ struct Fp_ {
         return o == 0;
     }
     FF_HD bool operator!=(const Fp_ &b) const { return !(*this == b); }
+    // the limbs, read as an integer, are below the modulus
+    FF_HD bool below_modulus() const {
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) borrow = (((uint64_t)v[i] - P::mod(i) - borrow) >> 32) & 1;
+        return borrow != 0;
+    }
 
     // r = a - p if a >= p else a   (a < 2p)
     FF_HD static Fp_ reduce_once(const Fp_ &a) {

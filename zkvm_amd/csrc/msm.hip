@@ -25,6 +25,7 @@
 #include "fq28.cuh"
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace zk {
 
@@ -812,6 +813,40 @@ void MsmEngine::export_points(uint64_t *xy_host, uint8_t *infinity_host, size_t 
             Fq one = Fq::one();
             memcpy(xy_host + 12 * i + 6, one.v, 48);
         }
+    }
+}
+
+void MsmEngine::load_points_raw(const uint8_t *bytes, size_t len) {
+    ZK_REQUIRE(bytes != nullptr && len >= 8, ZKGPU_ERR_INVALID_ARG, "srs_load_raw: need at least the 8-byte count");
+    uint64_t count = 0;
+    for (int k = 0; k < 8; k++) count |= (uint64_t)bytes[k] << (8 * k);
+    const uint64_t present = (len - 8) / 97;
+    if (count > present) count = present;   // chunks_exact(..).zip(0..len) stops at the shorter of the two
+    std::vector<uint64_t> xy((size_t)count * 12);
+    std::vector<uint8_t> inf((size_t)count);
+    for (uint64_t i = 0; i < count; i++) {
+        const uint8_t *p = bytes + 8 + 97 * i;
+        for (int w = 0; w < 12; w++) {
+            uint64_t v = 0;
+            for (int k = 0; k < 8; k++) v |= (uint64_t)p[8 * w + k] << (8 * k);
+            xy[12 * i + w] = v;
+        }
+        inf[i] = p[96] ? 1 : 0;
+    }
+    load_points(xy.data(), inf.data(), (size_t)count);
+}
+
+void MsmEngine::export_points_raw(uint8_t *out) {
+    const size_t n = n_points_;
+    std::vector<uint64_t> xy(n * 12);
+    std::vector<uint8_t> inf(n);
+    export_points(xy.data(), inf.data(), n);
+    for (int k = 0; k < 8; k++) out[k] = (uint8_t)((uint64_t)n >> (8 * k));
+    for (size_t i = 0; i < n; i++) {
+        uint8_t *p = out + 8 + 97 * i;
+        for (int w = 0; w < 12; w++)
+            for (int k = 0; k < 8; k++) p[8 * w + k] = (uint8_t)(xy[12 * i + w] >> (8 * k));
+        p[96] = inf[i];
     }
 }
 

@@ -23,6 +23,11 @@ class MsmEngine {
     void setup_powers(const Fr &tau, const G1Affine &g, size_t n);
     // Copies the first n loaded points back in the reference form (identity = (0, 1) + flag).
     void export_points(uint64_t *xy_host, uint8_t *infinity_host, size_t n);
+    // CommitKey::to_raw_var_bytes / from_slice_unchecked (kzg10/key.rs:38-66): a little-endian u64 count, then 97
+    // bytes per point (x | y as Montgomery limbs, infinity byte).  raw_size() = 8 + 97 * n_points().
+    void load_points_raw(const uint8_t *bytes, size_t len);
+    size_t raw_size() const { return 8 + 97 * n_points_; }
+    void export_points_raw(uint8_t *out);
     size_t n_points() const { return n_points_; }
 
     // sum_i scalars[i] * points[base + i], i < n.  `scalars_dev` holds n Fr elements in Montgomery form

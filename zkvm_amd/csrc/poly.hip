@@ -446,6 +446,42 @@ void PolyEngine::zero_and_scatter(Fr *dst, uint64_t len, const uint64_t *idx_hos
     ZK_HIP(hipStreamSynchronize(stream_));   // the host arrays are the caller's temporaries
 }
 
+// ---- canonical bytes <-> Montgomery form ----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) from_canonical_kernel(const Fr *raw, uint64_t count, Fr *out, uint64_t pad_to,
+                                                             unsigned int *bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pad_to) return;
+    if (i >= count) {
+        st(out + i, Fr::zero());
+        return;
+    }
+    const Fr a = ld(raw + i);
+    if (!a.below_modulus()) atomicOr(bad, 1u);
+    st(out + i, Fr::to_mont(a));
+}
+__global__ void __launch_bounds__(256) to_canonical_kernel(const Fr *in, uint64_t count, Fr *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) st(out + i, Fr::from_mont(ld(in + i)));
+}
+bool PolyEngine::from_canonical(const Fr *raw, uint64_t count, Fr *out, uint64_t pad_to) {
+    if (pad_to < count) pad_to = count;
+    if (!pad_to) return true;
+    s3_.reserve(64);
+    unsigned int *bad = s3_.as<unsigned int>();
+    ZK_HIP(hipMemsetAsync(bad, 0, 4, stream_));
+    hipLaunchKernelGGL(from_canonical_kernel, dim3(ceil_div(pad_to, 256)), dim3(256), 0, stream_, raw, count, out, pad_to, bad);
+    ZK_HIP(hipGetLastError());
+    unsigned int flag = 0;
+    ZK_HIP(hipMemcpyAsync(&flag, bad, 4, hipMemcpyDeviceToHost, stream_));
+    ZK_HIP(hipStreamSynchronize(stream_));
+    return flag == 0;
+}
+void PolyEngine::to_canonical(const Fr *in, uint64_t count, Fr *out_raw) {
+    if (!count) return;
+    hipLaunchKernelGGL(to_canonical_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, stream_, in, count, out_raw);
+    ZK_HIP(hipGetLastError());
+}
+
 // ---- degree -------------------------------------------------------------------------------------------------
 // *out = 1 + index of the highest non-zero coefficient (0 for the zero polynomial)
 __global__ void __launch_bounds__(1024) degree_kernel(const Fr *coeffs, uint64_t len, unsigned long long *out) {

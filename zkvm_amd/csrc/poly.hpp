@@ -66,6 +66,11 @@ class PolyEngine {
     // plonk/src/fft/polynomial.rs:95-103); synchronises the stream
     // dst[0..len) = 0, then dst[idx[k]] = vals[k] for distinct indexes below len (host arrays)
     void zero_and_scatter(Fr *dst, uint64_t len, const uint64_t *idx_host, const Fr *vals_host, uint32_t count);
+    // BlsScalar::from_bytes / to_bytes element-wise (coset-bls12_381/src/scalar.rs:256-305): `raw` holds count
+    // canonical integers of 32 little-endian bytes; out receives their Montgomery forms followed by zeros up to
+    // pad_to.  Returns false when a value is not below the modulus (the reference's Err on such bytes).
+    bool from_canonical(const Fr *raw, uint64_t count, Fr *out, uint64_t pad_to);
+    void to_canonical(const Fr *in, uint64_t count, Fr *out_raw);
     uint64_t length_without_leading_zeros(const Fr *coeffs, uint64_t len);
     // the same for up to 8 vectors with a single synchronisation
     void lengths_without_leading_zeros(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, uint64_t *out);

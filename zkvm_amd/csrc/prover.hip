@@ -151,6 +151,39 @@ void Prover::set_sharding(uint64_t shard_base, uint64_t total_points, uint32_t w
     world_ = fn ? world : 1;
 }
 
+// compiler.rs:303-306: linear_evaluations = coset_fft([0, 1]); L1 = coset_fft(ifft([1, 0, 0, ...]))
+// (quotient_poly.rs:237-245 builds alpha^2 * L1 per proof; alpha^2 is applied inside the quotient kernel);
+// compute_vanishing_poly_over_coset (domain.rs:256-275): v_h[i] = g^n * w_8n^(n i) - 1, period 8.
+void Prover::build_l1_and_vanishing(bool with_linear) {
+    const uint32_t n = n_, log_n = log_n_;
+    const size_t N8 = (size_t)8 * n;
+    Fr *evals = evals_.as<Fr>();
+    Fr *tmp = work_.as<Fr>();
+    if (with_linear) {
+        std::vector<Fr> two(2);
+        two[0] = Fr::zero();
+        two[1] = Fr::one();
+        ZK_HIP(hipMemcpyAsync(tmp, two.data(), 2 * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+        ZK_HIP(hipStreamSynchronize(stream_));
+        ntt_.transform(NTT_COSET_FFT, tmp, 2, evals + (size_t)N_SEL * N8, log_n + 3);
+    }
+    Fr one = Fr::one();
+    ZK_HIP(hipMemcpyAsync(tmp, &one, sizeof(Fr), hipMemcpyHostToDevice, stream_));
+    ZK_HIP(hipStreamSynchronize(stream_));
+    ntt_.transform(NTT_IFFT, tmp, 1, tmp, log_n);
+    ntt_.transform(NTT_COSET_FFT, tmp, n, evals + (size_t)(N_SEL + 1) * N8, log_n + 3);
+    Domain d8 = Domain::make(N8);
+    Fr g = Fr::inv(d8.generator_inv);
+    Fr gn = Fr::pow_u64(g, n);
+    Fr w8 = Fr::pow_u64(d8.group_gen, n);
+    Fr cur = Fr::one();
+    for (int i = 0; i < 8; i++) {
+        vh_[i] = Fr::sub(Fr::mul(gn, cur), Fr::one());
+        vh_inv_[i] = Fr::inv(vh_[i]);
+        cur = Fr::mul(cur, w8);
+    }
+}
+
 void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector_evals_host, const std::string &label,
                       const uint64_t *pi_indexes, size_t n_pi) {
     ZK_REQUIRE(n >= 1 && (n & (n - 1)) == 0, ZKGPU_ERR_INVALID_ARG, "prover_key_load: n must be a power of two");
@@ -187,34 +220,7 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
     if (poly_len_[Q_LOGIC]) widgets_ |= 2u;
     if (poly_len_[Q_FIXED]) widgets_ |= 4u;
     if (poly_len_[Q_VAR]) widgets_ |= 8u;
-    {
-        // compiler.rs:303-306: linear_evaluations = coset_fft([0, 1]) ; L1 = coset_fft(ifft([1, 0, 0, ...]))
-        // (quotient_poly.rs:237-245 builds alpha^2 * L1 per proof; alpha^2 is applied inside the quotient kernel)
-        std::vector<Fr> two(2);
-        two[0] = Fr::zero();
-        two[1] = Fr::one();
-        Fr *tmp = stage;  // selector staging is no longer needed
-        ZK_HIP(hipMemcpyAsync(tmp, two.data(), 2 * sizeof(Fr), hipMemcpyHostToDevice, stream_));
-        ZK_HIP(hipStreamSynchronize(stream_));
-        ntt_.transform(NTT_COSET_FFT, tmp, 2, evals + (size_t)N_SEL * N8, log_n + 3);
-        Fr one = Fr::one();
-        ZK_HIP(hipMemcpyAsync(tmp, &one, sizeof(Fr), hipMemcpyHostToDevice, stream_));
-        ZK_HIP(hipStreamSynchronize(stream_));
-        ntt_.transform(NTT_IFFT, tmp, 1, tmp, log_n);
-        ntt_.transform(NTT_COSET_FFT, tmp, n, evals + (size_t)(N_SEL + 1) * N8, log_n + 3);
-    }
-    {
-        // compute_vanishing_poly_over_coset (domain.rs:256-275): v_h[i] = g^n * w_8n^(n i) - 1, period 8
-        Domain d8 = Domain::make(N8);
-        Fr g = Fr::inv(d8.generator_inv);
-        Fr gn = Fr::pow_u64(g, n);
-        Fr w8 = Fr::pow_u64(d8.group_gen, n);
-        Fr cur = Fr::one();
-        for (int i = 0; i < 8; i++) {
-            vh_inv_[i] = Fr::inv(Fr::sub(Fr::mul(gn, cur), Fr::one()));
-            cur = Fr::mul(cur, w8);
-        }
-    }
+    build_l1_and_vanishing(true);
     // compiler.rs:152-171: selector commitments default to the identity on error, sigma commitments must succeed
     for (int k = 0; k < N_SEL; k++) {
         int rc = commit_dev(polys + (size_t)k * n, poly_len_[k], sel_comms_[k]);
@@ -226,6 +232,296 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
             sel_comms_[k] = affine_identity();
         }
     }
+}
+
+// ---- key (de)serialization --------------------------------------------------------------------------------------
+static uint64_t rd_be64(const uint8_t *p) {
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++) v = (v << 8) | p[i];
+    return v;
+}
+static uint64_t rd_le64(const uint8_t *p) {
+    uint64_t v = 0;
+    for (int i = 7; i >= 0; i--) v = (v << 8) | p[i];
+    return v;
+}
+static void wr_be64(uint8_t *p, uint64_t v) {
+    for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * (7 - i)));
+}
+static void wr_le64(uint8_t *p, uint64_t v) {
+    for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i));
+}
+// Order in which ProverKey::to_var_bytes and VerifierKey::to_bytes walk the selectors (widget.rs:82-97,294-365):
+// q_logic before q_range.
+static const int SERIAL_ORDER[N_SEL] = {Q_M, Q_L, Q_R, Q_O, Q_F, Q_C, Q_ARITH, Q_LOGIC, Q_RANGE, Q_FIXED, Q_VAR, S1, S2, S3, S4};
+static const size_t DOMAIN_BYTES = 172;   // EvaluationDomain::SIZE (fft/domain.rs:46): u64 + u32 + 5 scalars
+
+// y > (p - 1) / 2 for a canonical y (fp.rs:264-278)
+static bool fq_lex_largest(const Fq &y_mont) {
+    const Fq y = Fq::from_mont(y_mont);
+    // 2y > p  <=>  y > (p - 1) / 2 for odd p: compare 2y against p limb by limb
+    uint32_t twice[13];
+    uint32_t carry = 0;
+    for (int i = 0; i < 12; i++) {
+        twice[i] = (y.v[i] << 1) | carry;
+        carry = y.v[i] >> 31;
+    }
+    twice[12] = carry;
+    if (twice[12]) return true;
+    for (int i = 11; i >= 0; i--) {
+        if (twice[i] != Fq::mod_limb(i)) return twice[i] > Fq::mod_limb(i);
+    }
+    return false;
+}
+// G1Affine::from_bytes (coset-bls12_381/src/g1/coset.rs:73-140): compressed x with the three flag bits, y from the
+// curve equation, sign from the sort flag, then the subgroup check.  Returns false where the reference returns Err.
+static bool g1_decompress(const uint8_t in[48], AffineOut &out) {
+    const bool compressed = (in[0] >> 7) & 1, infinity = (in[0] >> 6) & 1, sort = (in[0] >> 5) & 1;
+    if (!compressed) return false;
+    Fq xc;
+    for (int i = 0; i < 12; i++) {
+        uint32_t limb = 0;
+        for (int b = 0; b < 4; b++) {
+            uint8_t byte = in[4 * i + b];
+            if (i == 0 && b == 0) byte &= 0x1f;
+            limb = (limb << 8) | byte;
+        }
+        xc.v[11 - i] = limb;
+    }
+    if (!xc.below_modulus()) return false;
+    if (infinity) {
+        if (sort || !xc.is_zero()) return false;
+        out = affine_identity();
+        return true;
+    }
+    const Fq x = Fq::to_mont(xc);
+    Fq four = Fq::zero();
+    four.v[0] = 4;
+    const Fq rhs = Fq::add(Fq::mul(Fq::mul(x, x), x), Fq::to_mont(four));
+    // p = 3 mod 4: the root, if any, is rhs^((p + 1) / 4)
+    uint32_t e[12];
+    uint64_t carry = 1;
+    for (int i = 0; i < 12; i++) {
+        uint64_t t = (uint64_t)Fq::mod_limb(i) + carry;
+        e[i] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    for (int i = 0; i < 12; i++) e[i] = (e[i] >> 2) | (i + 1 < 12 ? e[i + 1] << 30 : 0);
+    Fq y = Fq::pow(rhs, e, 12);
+    if (Fq::mul(y, y) != rhs) return false;
+    if (fq_lex_largest(y) != sort) y = Fq::neg(y);
+    // subgroup check: [r] P is the identity
+    G1Affine pa;
+    pa.x = x;
+    pa.y = y;
+    G1Proj acc = G1Proj::identity();
+    for (int i = 254; i >= 0; i--) {
+        acc = g1_double(acc);
+        if ((Fr::mod_limb(i >> 5) >> (i & 31)) & 1) acc = g1_add_mixed(acc, pa);
+    }
+    if (!acc.z.is_zero()) return false;
+    out.x = x;
+    out.y = y;
+    out.infinity = false;
+    return true;
+}
+
+void Prover::load_key_bytes(const uint8_t *b, size_t len, const uint64_t *pi_indexes, size_t n_pi) {
+    ZK_REQUIRE(b != nullptr && len >= 48, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: NotEnoughBytes (48-byte header)");
+    const uint64_t label_len = rd_be64(b), pk_len = rd_be64(b + 8), ck_len = rd_be64(b + 16), vk_len = rd_be64(b + 24),
+                   size = rd_be64(b + 32), constraints = rd_be64(b + 40);
+    const uint64_t rest = len - 48;
+    ZK_REQUIRE(label_len <= rest && pk_len <= rest - label_len && ck_len <= rest - label_len - pk_len &&
+                   vk_len <= rest - label_len - pk_len - ck_len,
+               ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: NotEnoughBytes (pieces longer than the input)");
+    const uint8_t *label = b + 48, *pk = label + label_len, *ck = pk + pk_len, *vk = ck + ck_len;
+
+    // VerifierKey::from_slice (widget.rs:102-123)
+    ZK_REQUIRE(vk_len >= 8 + 48 * N_SEL, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: verifier key too short");
+    AffineOut comms[N_SEL];
+    for (int j = 0; j < N_SEL; j++)
+        ZK_REQUIRE(g1_decompress(vk + 8 + 48 * j, comms[SERIAL_ORDER[j]]), ZKGPU_ERR_INVALID_ARG,
+                   "prover_load_bytes: a verifier-key commitment is not a valid compressed G1 point");
+
+    // ProverKey::from_slice (widget.rs:374-519): header, then walk the pieces to validate before touching the device
+    ZK_REQUIRE(pk_len >= 16, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: prover key too short");
+    const uint64_t n64 = rd_le64(pk), eval_size = rd_le64(pk + 8);
+    ZK_REQUIRE(n64 >= 1 && (n64 & (n64 - 1)) == 0 && n64 * 8 < (1ull << 32), ZKGPU_ERR_DOMAIN_SIZE,
+               "prover_load_bytes: the key's size is not a power of two below 2^29");
+    ZK_REQUIRE(size == n64, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: header size and prover key size differ");
+    const uint32_t n = (uint32_t)n64;
+    const size_t N8 = (size_t)8 * n;
+    ZK_REQUIRE(eval_size == DOMAIN_BYTES + N8 * 32, ZKGPU_ERR_INVALID_ARG,
+               "prover_load_bytes: evaluation vectors are not over the 8n domain");
+    const uint8_t *poly_at[N_SEL], *eval_at[N_SEL + 2];
+    uint64_t coeffs[N_SEL];
+    uint64_t pos = 16;
+    for (int j = 0; j < N_SEL; j++) {
+        ZK_REQUIRE(pk_len - pos >= 8, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: prover key truncated");
+        coeffs[j] = rd_le64(pk + pos);
+        pos += 8;
+        ZK_REQUIRE(coeffs[j] <= n && (pk_len - pos) / 32 >= coeffs[j] && pk_len - pos - coeffs[j] * 32 >= eval_size,
+                   ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: prover key truncated or a polynomial longer than n");
+        poly_at[j] = pk + pos;
+        pos += coeffs[j] * 32;
+        eval_at[j] = pk + pos;
+        pos += eval_size;
+    }
+    for (int j = N_SEL; j < N_SEL + 2; j++) {
+        ZK_REQUIRE(pk_len - pos >= eval_size, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: prover key truncated");
+        eval_at[j] = pk + pos;
+        pos += eval_size;
+    }
+    for (int j = 0; j < N_SEL + 2; j++)
+        ZK_REQUIRE(rd_le64(eval_at[j]) == N8, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: an evaluation vector names another domain");
+
+    // CommitKey::from_slice_unchecked (kzg10/key.rs:54-66)
+    n_ = 0;
+    msm_.load_points_raw(ck, ck_len);
+    ZK_REQUIRE(msm_.n_points() > 0, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: empty commit key");
+
+    uint32_t log_n = 0;
+    while ((1u << log_n) < n) log_n++;
+    polys_.reserve((size_t)N_SEL * n * sizeof(Fr));
+    evals_.reserve((size_t)(N_SEL + 2) * N8 * sizeof(Fr));
+    sigma_.reserve((size_t)4 * n * sizeof(Fr));
+    work_.reserve((size_t)N_SEL * n * sizeof(Fr));   // >= 8n elements of staging
+    Fr *stage = work_.as<Fr>();
+    Fr *polys = polys_.as<Fr>();
+    Fr *evals = evals_.as<Fr>();
+    log_n_ = log_n;
+    bool canonical = true;
+    for (int j = 0; j < N_SEL + 1; j++) {
+        const int k = j < N_SEL ? SERIAL_ORDER[j] : N_SEL;   // the last one is linear_evaluations
+        if (j < N_SEL) {
+            if (coeffs[j]) ZK_HIP(hipMemcpyAsync(stage, poly_at[j], coeffs[j] * 32, hipMemcpyHostToDevice, stream_));
+            canonical &= poly_.from_canonical(stage, coeffs[j], polys + (size_t)k * n, n);
+            // Polynomial::from_slice drops leading zeros (fft/polynomial.rs:131-143)
+            poly_len_[k] = coeffs[j] ? poly_.length_without_leading_zeros(polys + (size_t)k * n, coeffs[j]) : 0;
+        }
+        ZK_HIP(hipMemcpyAsync(stage, eval_at[j] + DOMAIN_BYTES, N8 * 32, hipMemcpyHostToDevice, stream_));
+        canonical &= poly_.from_canonical(stage, N8, evals + (size_t)k * N8, N8);
+    }
+    ZK_REQUIRE(canonical, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: a scalar is not below the field modulus");
+    n_ = n;
+    constraints_ = constraints;
+    label_.assign(reinterpret_cast<const char *>(label), label_len);
+    pi_indexes_.assign(pi_indexes, pi_indexes + n_pi);
+    widgets_ = 0;
+    if (poly_len_[Q_RANGE]) widgets_ |= 1u;
+    if (poly_len_[Q_LOGIC]) widgets_ |= 2u;
+    if (poly_len_[Q_FIXED]) widgets_ |= 4u;
+    if (poly_len_[Q_VAR]) widgets_ |= 8u;
+    for (int k = 0; k < N_SEL; k++) sel_comms_[k] = comms[k];
+    // the sigma values over the n domain, which compute_permutation_vec re-derives from the polynomials
+    // (composer/permutation.rs:189-199)
+    for (int k = 0; k < 4; k++)
+        ntt_.transform(NTT_FFT, polys + (size_t)(S1 + k) * n, poly_len_[S1 + k], sigma_.as<Fr>() + (size_t)k * n, log_n);
+    build_l1_and_vanishing(false);
+    // v_h_coset_8n has period 8 (domain.rs:256-275); the stored vector must be the one of this domain
+    for (int i = 0; i < 8; i++) {
+        Fr raw;
+        memcpy(raw.v, eval_at[N_SEL + 1] + DOMAIN_BYTES + 32 * i, 32);
+        if (!raw.below_modulus() || Fr::to_mont(raw) != vh_[i]) {
+            n_ = 0;
+            throw ZkError(ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: v_h_coset_8n does not belong to the 8n coset");
+        }
+    }
+    ZK_HIP(hipStreamSynchronize(stream_));
+}
+
+size_t Prover::to_bytes(uint8_t *out, size_t cap) {
+    ZK_REQUIRE(n_ != 0, ZKGPU_ERR_NOT_LOADED, "prover_to_bytes: no key loaded");
+    const uint32_t n = n_;
+    const size_t N8 = (size_t)8 * n;
+    const size_t eval_size = DOMAIN_BYTES + N8 * 32;
+    // ProverKey::serialization_size (widget.rs:265-278): every polynomial is budgeted at q_m's length
+    const size_t pk_size = (size_t)poly_len_[Q_M] * 32 * 15 + eval_size * 17 + 8 * 17;
+    const size_t ck_size = msm_.raw_size(), vk_size = 8 + 48 * N_SEL;
+    const size_t total = 48 + label_.size() + pk_size + ck_size + vk_size;
+    if (out == nullptr || cap < total) return total;
+    wr_be64(out, label_.size());
+    wr_be64(out + 8, pk_size);
+    wr_be64(out + 16, ck_size);
+    wr_be64(out + 24, vk_size);
+    wr_be64(out + 32, n);
+    wr_be64(out + 40, constraints_);
+    memcpy(out + 48, label_.data(), label_.size());
+    uint8_t *pk = out + 48 + label_.size();
+    memset(pk, 0, pk_size);
+    // writes follow coset-bytes' slice writer (bytes/src/serialize.rs:105-118): a piece that does not fit in what
+    // is left of the budget is dropped as a whole
+    size_t pos = 0;
+    auto fits = [&](size_t bytes) { return bytes <= pk_size - pos; };
+    auto put_u64 = [&](uint64_t v) {
+        if (!fits(8)) return;
+        wr_le64(pk + pos, v);
+        pos += 8;
+    };
+    uint8_t dom[DOMAIN_BYTES];
+    {
+        Domain d8 = Domain::make(N8);
+        wr_le64(dom, d8.size);
+        for (int i = 0; i < 4; i++) dom[8 + i] = (uint8_t)(d8.log_size >> (8 * i));
+        const Fr *f[5] = {&d8.size_as_field_element, &d8.size_inv, &d8.group_gen, &d8.group_gen_inv, &d8.generator_inv};
+        for (int k = 0; k < 5; k++) {
+            Fr c = Fr::from_mont(*f[k]);
+            memcpy(dom + 12 + 32 * k, c.v, 32);
+        }
+    }
+    work_.reserve((size_t)N_SEL * n * sizeof(Fr));
+    Fr *stage = work_.as<Fr>();
+    auto put_scalars = [&](const Fr *dev, size_t count, bool with_domain) {
+        const size_t bytes = count * 32 + (with_domain ? DOMAIN_BYTES : 0);
+        if (!fits(bytes)) return;
+        if (with_domain) {
+            memcpy(pk + pos, dom, DOMAIN_BYTES);
+            pos += DOMAIN_BYTES;
+        }
+        if (count) {
+            poly_.to_canonical(dev, count, stage);
+            ZK_HIP(hipMemcpyAsync(pk + pos, stage, count * 32, hipMemcpyDeviceToHost, stream_));
+            ZK_HIP(hipStreamSynchronize(stream_));
+            pos += count * 32;
+        }
+    };
+    put_u64(n);
+    put_u64(eval_size);
+    const Fr *polys = polys_.as<Fr>();
+    const Fr *evals = evals_.as<Fr>();
+    for (int j = 0; j < N_SEL; j++) {
+        const int k = SERIAL_ORDER[j];
+        put_u64(poly_len_[k]);
+        put_scalars(polys + (size_t)k * n, poly_len_[k], false);
+        put_scalars(evals + (size_t)k * N8, N8, true);
+    }
+    put_scalars(evals + (size_t)N_SEL * N8, N8, true);
+    if (fits(eval_size)) {   // v_h_coset_8n: the eight values, repeated
+        memcpy(pk + pos, dom, DOMAIN_BYTES);
+        pos += DOMAIN_BYTES;
+        uint8_t period[8 * 32];
+        for (int i = 0; i < 8; i++) {
+            Fr c = Fr::from_mont(vh_[i]);
+            memcpy(period + 32 * i, c.v, 32);
+        }
+        for (size_t i = 0; i < N8; i += 8) {
+            const size_t chunk = N8 - i < 8 ? N8 - i : 8;
+            memcpy(pk + pos, period, chunk * 32);
+            pos += chunk * 32;
+        }
+    }
+    uint8_t *ck = pk + pk_size;
+    msm_.export_points_raw(ck);
+    uint8_t *vk = ck + ck_size;
+    wr_le64(vk, constraints_);
+    for (int j = 0; j < N_SEL; j++) {
+        const AffineOut &c = sel_comms_[SERIAL_ORDER[j]];
+        uint64_t xy[12];
+        memcpy(xy, c.x.v, 48);
+        memcpy(xy + 6, c.y.v, 48);
+        zkgpu_g1_compress(xy, c.infinity ? 1 : 0, vk + 8 + 48 * j);
+    }
+    return total;
 }
 
 void Prover::blind_poly(const Fr *evals_dev, int hiding_degree, const Fr *blinders, Fr *out_dev) {

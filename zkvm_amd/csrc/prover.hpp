@@ -39,6 +39,13 @@ class Prover {
     // composer/permutation.rs:111-141).  Requires the SRS to be loaded.
     void load_key(uint32_t n, uint64_t constraints, const uint64_t *selector_evals_host, const std::string &label,
                   const uint64_t *pi_indexes, size_t n_pi);
+    // Prover::try_from_bytes (compiler/prover.rs:137-207) straight into device memory: label, ProverKey
+    // (widget.rs:374-519), CommitKey (kzg10/key.rs:54-66, replaces the loaded SRS) and VerifierKey
+    // (widget.rs:102-123).  The reference keeps the public input positions in the circuit, not in these bytes, so
+    // they are passed beside them.  Malformed input throws ZKGPU_ERR_INVALID_ARG where the reference returns Err.
+    void load_key_bytes(const uint8_t *bytes, size_t len, const uint64_t *pi_indexes, size_t n_pi);
+    // Prover::to_bytes (compiler/prover.rs:85-134) of the loaded key; returns the size and writes when cap suffices.
+    size_t to_bytes(uint8_t *out, size_t cap);
     // Point-range sharding of every commitment over several contexts (one per GPU): `fn(user, mine, m, all)` must
     // all-gather m partial sums of 18 limbs each into all[rank][m][18]; nullptr switches sharding off.
     typedef int (*ExchangeFn)(void *user, const uint64_t *mine, size_t m, uint64_t *all);
@@ -67,6 +74,7 @@ class Prover {
     int commit_dev(const Fr *coeffs, uint64_t len, AffineOut &out);
     int commit_many(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, AffineOut *out);
     void blind_poly(const Fr *evals_dev, int hiding_degree, const Fr *blinders, Fr *out_dev);
+    void build_l1_and_vanishing(bool with_linear);
 
     hipStream_t stream_;
     NttEngine &ntt_;
@@ -82,7 +90,7 @@ class Prover {
     std::vector<uint64_t> pi_indexes_;
     uint64_t poly_len_[N_SEL] = {0};
     uint32_t widgets_ = 0;
-    Fr vh_inv_[8];
+    Fr vh_[8], vh_inv_[8];   // the 8 distinct values of Z_H on the 8n coset and their inverses
     AffineOut sel_comms_[N_SEL];
     DevBuf polys_;   // N_SEL x n coefficients
     DevBuf evals_;   // (N_SEL + 2) x 8n: selector coset evaluations, X on the coset, L1 on the coset

@@ -119,6 +119,40 @@ struct Fq28 {
         return r;
     }
 
+    // (a * b + c * d) * 2^-392 mod p with ONE reduction, normalised and below 2p.  Preconditions: the column sums of
+    // both products together fit 64 bits (e.g. limbs 1.5 * 2^29 x 1.5 * 2^29 plus 2^28 x 2^28) and
+    // value(a) value(b) + value(c) value(d) < 2^392 * p.
+    FF_HD static Fq28 mul_add(const Fq28 &a, const Fq28 &b, const Fq28 &c2, const Fq28 &d) {
+        Fq28 r;
+        uint32_t m[14];
+        uint64_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) c += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+            for (int i = 0; i <= k; i++) c += (uint64_t)c2.v[i] * d.v[k - i];
+#pragma unroll
+            for (int i = 0; i < k; i++) c += (uint64_t)m[i] * P(k - i);
+            m[k] = ((uint32_t)c * PINV) & MASK;
+            c += (uint64_t)m[k] * P(0);
+            c >>= 28;
+        }
+#pragma unroll
+        for (int k = 14; k < 27; k++) {
+#pragma unroll
+            for (int i = k - 13; i < 14; i++) c += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+            for (int i = k - 13; i < 14; i++) c += (uint64_t)c2.v[i] * d.v[k - i];
+#pragma unroll
+            for (int i = k - 13; i < 14; i++) c += (uint64_t)m[i] * P(k - i);
+            r.v[k - 14] = (uint32_t)c & MASK;
+            c >>= 28;
+        }
+        r.v[13] = (uint32_t)c;
+        return r;
+    }
+
     // a * a * 2^-392: the off-diagonal partial products are taken once against the doubled operand (105 products
     // instead of 196 before the reduction).  Same preconditions as mul(a, a).
     FF_HD static Fq28 sqr(const Fq28 &a) {
@@ -271,6 +305,7 @@ inline long &fq28_violations() {
 static __device__ __forceinline__ Fq28 fq28_mul_inlined(const Fq28 &a, const Fq28 &b) { return Fq28::mul(a, b); }
 __device__ __forceinline__ Fq28 m28(const Fq28 &a, const Fq28 &b) { return fq28_mul_inlined(a, b); }
 __device__ __forceinline__ Fq28 s28(const Fq28 &a) { return Fq28::sqr(a); }
+__device__ __forceinline__ Fq28 ma28(const Fq28 &a, const Fq28 &b, const Fq28 &c, const Fq28 &d) { return Fq28::mul_add(a, b, c, d); }
 #else
 // Host build: every product checks the preconditions of Fq28::mul and counts violations, so that the host-side
 // self-check of the bucket arithmetic also proves the limb and magnitude bounds on the inputs it sees.
@@ -287,6 +322,20 @@ inline Fq28 m28(const Fq28 &a, const Fq28 &b) {
     const double ta = (double)a.v[13] + (double)(a.v[12] >> 28) + 1.0, tb = (double)b.v[13] + (double)(b.v[12] >> 28) + 1.0;
     if (ta * tb >= 2.9e13) fq28_violations()++;   // value(a) * value(b) must stay below 2^392 * p
     return Fq28::mul(a, b);
+}
+inline Fq28 ma28(const Fq28 &a, const Fq28 &b, const Fq28 &c, const Fq28 &d) {
+    for (int k = 0; k < 27; k++) {
+        unsigned __int128 col = (unsigned __int128)1 << 37;
+        for (int i = 0; i < 14; i++) {
+            int j = k - i;
+            if (j < 0 || j > 13) continue;
+            col += (unsigned __int128)a.v[i] * b.v[j] + (unsigned __int128)c.v[i] * d.v[j] + (unsigned __int128)Fq28::MASK * Fq28::P(j);
+        }
+        if (col >> 64) fq28_violations()++;
+    }
+    auto top = [](const Fq28 &x) { return (double)x.v[13] + (double)(x.v[12] >> 28) + 1.0; };
+    if (top(a) * top(b) + top(c) * top(d) >= 2.9e13) fq28_violations()++;
+    return Fq28::mul_add(a, b, c, d);
 }
 inline Fq28 s28(const Fq28 &a) {
     Fq28 checked = m28(a, a);   // bounds check + reference result
@@ -346,7 +395,8 @@ FF_HD G1Xyzz xyzz_add_mixed(const G1Xyzz &acc, const G1Affine28 &p, bool negate)
     const Fq28 nq = Fq28::sub4(Fq28::zero(), q);
     r.x = Fq28::normalize(Fq28::add(Fq28::sub4(rr, ppp), Fq28::add(nq, nq)));   // rr - ppp - 2q, < 14p
     const Fq28 t = Fq28::sub16(q, r.x);
-    r.y = Fq28::normalize(Fq28::sub4(m28(rd, t), m28(acc.y, ppp)));            // < 6p
+    const Fq28 ny = Fq28::normalize(Fq28::sub16(Fq28::zero(), acc.y));         // 16p - y, limbs < 2^28
+    r.y = ma28(rd, t, ny, ppp);                                                // rd t - y ppp with one reduction, < 2p
     r.zz = zz3;
     r.zzz = m28(acc.zzz, ppp);
     return r;

@@ -20,6 +20,14 @@
 
 namespace zk {
 
+// Host builds of the bucket arithmetic count every broken precondition here (limb bounds of products, operands of
+// the biased subtractions); the device never calls it.
+inline long &fq28_violations() {
+    static long count = 0;
+    return count;
+}
+inline void note_violation() { fq28_violations()++; }
+
 struct Fq28 {
     static constexpr int N = 14;
     static constexpr uint32_t MASK = 0x0fffffffu;
@@ -197,12 +205,20 @@ struct Fq28 {
         Fq28 r;
 #pragma unroll
         for (int i = 0; i < 14; i++) r.v[i] = a.v[i] + (B4(i) - b.v[i]);
+#if !defined(__HIP_DEVICE_COMPILE__)
+        for (int i = 0; i < 14; i++)
+            if (b.v[i] > B4(i)) note_violation();   // host builds check the "normalised b" precondition
+#endif
         return r;
     }
     FF_HD static Fq28 sub16(const Fq28 &a, const Fq28 &b) {
         Fq28 r;
 #pragma unroll
         for (int i = 0; i < 14; i++) r.v[i] = a.v[i] + (B16(i) - b.v[i]);
+#if !defined(__HIP_DEVICE_COMPILE__)
+        for (int i = 0; i < 14; i++)
+            if (b.v[i] > B16(i)) note_violation();
+#endif
         return r;
     }
     // carry propagation: same value, limbs < 2^28 except the top one
@@ -292,11 +308,6 @@ struct G1Xyzz {
     FF_HD bool is_identity() const { return zz.limbs_zero(); }
 };
 
-// Host builds of the product check its preconditions and count violations here (see m28 below).
-inline long &fq28_violations() {
-    static long count = 0;
-    return count;
-}
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // Inlined on purpose: at ~510 instructions a product is small enough for the whole mixed addition (10 of them) to
@@ -359,7 +370,8 @@ FF_HD G1Xyzz xyzz_double_affine(const Fq28 &x, const Fq28 &y) {
     Fq28 d = Fq28::sub4(Fq28::zero(), s);        // 4p - s
     r.x = Fq28::normalize(Fq28::add(mm, Fq28::add(d, d)));        // mm - 2s, < 10p
     Fq28 t = Fq28::sub16(s, r.x);
-    r.y = Fq28::normalize(Fq28::sub4(m28(m, t), m28(w, y)));      // < 6p
+    const Fq28 ny = Fq28::normalize(Fq28::sub16(Fq28::zero(), Fq28::normalize(y)));   // y may come with lazy limbs
+    r.y = ma28(m, t, w, ny);                                       // < 2p
     r.zz = v;
     r.zzz = w;
     return r;
@@ -415,7 +427,8 @@ FF_HD G1Xyzz xyzz_double(const G1Xyzz &a) {
     Fq28 d = Fq28::sub4(Fq28::zero(), s);
     r.x = Fq28::normalize(Fq28::add(mm, Fq28::add(d, d)));        // < 10p
     Fq28 t = Fq28::sub16(s, r.x);
-    r.y = Fq28::normalize(Fq28::sub4(m28(m, t), m28(w, a.y)));    // < 6p
+    const Fq28 ny = Fq28::normalize(Fq28::sub16(Fq28::zero(), a.y));
+    r.y = ma28(m, t, w, ny);                                       // < 2p
     r.zz = m28(v, a.zz);
     r.zzz = m28(w, a.zzz);
     return r;
@@ -445,7 +458,8 @@ FF_HD G1Xyzz xyzz_add(const G1Xyzz &a, const G1Xyzz &b) {
     const Fq28 nq = Fq28::sub4(Fq28::zero(), q);
     r.x = Fq28::normalize(Fq28::add(Fq28::sub4(rr, ppp), Fq28::add(nq, nq)));   // < 14p
     const Fq28 t = Fq28::sub16(q, r.x);
-    r.y = Fq28::normalize(Fq28::sub4(m28(rd, t), m28(s1, ppp)));               // < 6p
+    const Fq28 ns1 = Fq28::normalize(Fq28::sub4(Fq28::zero(), s1));            // 4p - s1, limbs < 2^28
+    r.y = ma28(rd, t, ns1, ppp);                                               // < 2p
     r.zz = zz3;
     r.zzz = m28(m28(a.zzz, b.zzz), ppp);
     return r;

@@ -313,6 +313,8 @@ def run_prove(args, rank, world, local, device):
         sharding.srs_setup_range(ctx, circuits.seeded_tau(), circuits.g1_generator_limbs(), base, count)
         sharding.enable_prover_sharding(ctx, base, n + 7, comm_device(device))
     else:
+        if args.msm_window:
+            ctx.msm_set_params(args.msm_window, 0)
         ctx.srs_setup(circuits.seeded_tau(), circuits.g1_generator_limbs(), n + 7)   # tau^i * G, generated on the device
     ctx.sync()
     t_srs = time.perf_counter() - t0
@@ -400,6 +402,7 @@ def main():
                     help="prove workload on N > 1 GPUs: one proof at a time with point-range sharded commitments "
                          "(strong scaling) instead of independent proofs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--msm-window", type=int, default=0, help="tuning: force the MSM window width (0 = the engine's choice)")
     args = ap.parse_args()
 
     import torch

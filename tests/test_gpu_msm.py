@@ -213,3 +213,26 @@ def test_msm_2_22_properties(ctx, orc):
     other = ctx.msm_partial(torch.from_numpy(neg.view(np.int64)).cuda(), 0)
     _, inf3 = zkvm_amd.g1_sum_to_affine(np.stack([whole, other]))
     assert inf3 == 1
+
+
+def test_short_top_window_goes_through_the_task_path(ctx, orc):
+    """255 = 14 * 18 + 3: with an 18-bit window the top digits of all scalars fall on 8 buckets.  Those must be cut into
+    workgroup tasks; left to one thread each they are chains of n/8 dependent additions (a hundred times slower)."""
+    import time
+    import torch
+    n = 1 << 16
+    pts, _ = orc.g1_multiples_of_generator(9, n)
+    sc = M.random_fr_mont(n, 55)
+    try:
+        ctx.msm_set_params(18, 0)
+        ctx.srs_load(pts)
+        sd = torch.from_numpy(sc.view(np.int64)).cuda()
+        got_xy, got_inf = ctx.msm(sd)
+        t0 = time.perf_counter()
+        ctx.msm(sd)
+        elapsed = time.perf_counter() - t0
+    finally:
+        ctx.msm_set_params(0, 0)
+    want_xy, want_inf = oracle_affine(orc, pts, sc)
+    assert got_inf == want_inf and np.array_equal(got_xy, want_xy)
+    assert elapsed < 0.03, elapsed

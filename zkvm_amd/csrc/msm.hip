@@ -880,7 +880,12 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     // stay below that.  The chain of a longer bucket on one thread would be the tail of the accumulate launch.
     const uint32_t top_bits = 255 - (K - 1) * c;
     uint64_t expect = max_items >> log_B;
-    if (top_bits < log_B) expect += (max_items / K) >> top_bits;
+    if (top_bits < log_B) {
+        // a modest share stays with the bucket's thread; a large one (few top-window values) makes those buckets
+        // oversized, as choose_window's model assumes
+        const uint64_t extra = (max_items / K) >> top_bits;
+        if (extra <= 4 * expect + BIG_BUCKET) expect += extra;
+    }
     uint64_t big64 = expect + 16 + (uint64_t)(8.0 * std::sqrt((double)expect));
     uint32_t class_shift = 0;   // size classes are count >> shift, shift the smallest with big <= 256 << shift
     while (((uint64_t)BIG_BUCKET << class_shift) < big64 && class_shift < 12) class_shift++;

@@ -313,8 +313,8 @@ def run_prove(args, rank, world, local, device):
         sharding.srs_setup_range(ctx, circuits.seeded_tau(), circuits.g1_generator_limbs(), base, count)
         sharding.enable_prover_sharding(ctx, base, n + 7, comm_device(device))
     else:
-        if args.msm_window:
-            ctx.msm_set_params(args.msm_window, 0)
+        if args.msm_window or args.msm_segment:
+            ctx.msm_set_params(args.msm_window, args.msm_segment)
         ctx.srs_setup(circuits.seeded_tau(), circuits.g1_generator_limbs(), n + 7)   # tau^i * G, generated on the device
     ctx.sync()
     t_srs = time.perf_counter() - t0
@@ -403,6 +403,7 @@ def main():
                          "(strong scaling) instead of independent proofs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-window", type=int, default=0, help="tuning: force the MSM window width (0 = the engine's choice)")
+    ap.add_argument("--msm-segment", type=int, default=0, help="tuning: log2 of the buckets per reduction segment (0 = default)")
     args = ap.parse_args()
 
     import torch

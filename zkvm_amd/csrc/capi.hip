@@ -248,7 +248,7 @@ int zkgpu_msm_set_params(zkgpu_ctx *ctx, uint32_t window_bits, uint32_t segment_
                    "msm_set_params: window_bits must be 0 or within 4..22");
         ZK_REQUIRE(segment_bits <= 6, ZKGPU_ERR_INVALID_ARG, "msm_set_params: segment_bits must be 0 or within 1..6");
         ctx->msm->set_window_override(window_bits);
-        ctx->msm->set_segment_bits(segment_bits ? segment_bits : 3);
+        ctx->msm->set_segment_bits(segment_bits);
     });
 }
 

@@ -894,7 +894,8 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     // every oversized bucket gives ceil(count / BIG_CHUNK) tasks: at most one per `big` entries plus one per chunk
     const uint32_t max_tasks = (uint32_t)(total_items / big + total_items / BIG_CHUNK + m);
     const uint32_t n_scan_blocks = ceil_div(nb, SCAN_ITEMS);
-    const uint32_t log_seg = log_B < seg_bits_ ? log_B : seg_bits_;
+    const uint32_t seg_bits = seg_bits_ ? seg_bits_ : (m >= 3 ? 4u : 3u);
+    const uint32_t log_seg = log_B < seg_bits ? log_B : seg_bits;
     const uint32_t segs_per_sum = 1u << (log_B - log_seg);
     const uint32_t n_bits = log_B - log_seg;
     const uint32_t groups = n_bits ? n_bits + 3 : 2;

@@ -54,6 +54,8 @@ class MsmEngine {
     size_t device_bytes() const;
     // Test hooks: window width used by the next load_points*, segment width of the bucket reduction.
     void set_window_override(uint32_t c) { window_override_ = c; }
+    // 0 = automatic: 8-bucket segments, 16-bucket ones for batches of three or four sums (whose reduction is bound by
+    // work rather than by the depth of its trees)
     void set_segment_bits(uint32_t b) { seg_bits_ = b; }
     uint32_t window_bits() const { return c_; }
     uint32_t n_windows() const { return K_; }
@@ -65,7 +67,7 @@ class MsmEngine {
     DevBuf points_;   // reference-form affine multiples, K levels (kept from the build)
     DevBuf table28_;  // table[w * n_points + i] = 2^(c w) * P_i, affine, unsaturated limbs (112 bytes), K levels
     size_t n_points_ = 0;
-    uint32_t c_ = 0, K_ = 0, seg_bits_ = 3;
+    uint32_t c_ = 0, K_ = 0, seg_bits_ = 0;
     DevBuf counts_, offsets_, cursor_, sorted_, buckets_, block_sums_, tasks_, partials_, misc_, seg_, group_sums_;
     DevBuf order_, digits_, range_cnt_, mid_;
     uint32_t window_override_ = 0;

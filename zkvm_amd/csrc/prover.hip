@@ -656,7 +656,7 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     }
     for (auto &pi : public_inputs) tr.append_scalar("pi", pi);  // prover.rs:236-238
 
-    // round 1: wire polynomials (prover.rs:240-269)
+    // protocol phase 1: wire polynomials (prover.rs:240-269)
     // hipMemcpyDefault: the caller's pointer may be host memory or already resident in HBM
     ZK_HIP(hipMemcpyAsync(wires, wires_host, 4 * n * sizeof(Fr), hipMemcpyDefault, stream_));
     Fr *wp[4] = {p_a, p_b, p_c, p_d};
@@ -673,7 +673,7 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     tr.append_commitment("d_comm", out.comms[3]);
     lap(0, t_phase);
 
-    // round 2: permutation accumulator (prover.rs:271-293)
+    // protocol phase 2: permutation accumulator (prover.rs:271-293)
     const Fr beta = tr.challenge_scalar("beta");
     tr.append_scalar("beta", beta);
     const Fr gamma = tr.challenge_scalar("gamma");
@@ -687,7 +687,7 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     tr.append_commitment("z_comm", out.comms[4]);
     lap(1, t_phase);
 
-    // round 3: quotient (prover.rs:295-361)
+    // protocol phase 3: quotient (prover.rs:295-361)
     const Fr alpha = tr.challenge_scalar("alpha");
     const Fr range_ch = tr.challenge_scalar("range separation challenge");
     const Fr logic_ch = tr.challenge_scalar("logic separation challenge");
@@ -746,7 +746,7 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     tr.append_commitment("t_fourth_comm", out.comms[8]);
     lap(3, t_phase);
 
-    // round 4: evaluations (prover.rs:363-437)
+    // protocol phase 4: evaluations (prover.rs:363-437)
     const Fr z_ch = tr.challenge_scalar("z_challenge");
     const Fr z_w = Fr::mul(z_ch, domain.group_gen);
     enum { A, B, C, D, AW, BW, DW, QARITH, QC, QL, QR, SG1, SG2, SG3, ZE };
@@ -794,7 +794,7 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     tr.append_scalar("q_r_eval", e[QR]);
     lap(4, t_phase);
 
-    // round 5: linearization (linearization_poly.rs:146-272) and openings (prover.rs:439-487)
+    // protocol phase 5: linearization (linearization_poly.rs:146-272) and openings (prover.rs:439-487)
     const Fr v_ch = tr.challenge_scalar("v_challenge");
     uint64_t r_len;
     {

@@ -125,3 +125,19 @@ def test_srs_raw_bytes_round_trip(ctx, orc):
     got = ctx.msm(sc)
     want = orc.g1_to_affine(orc.msm(pts[:7], sc, inf=inf[:7]))
     assert got[1] == int(want[1]) and np.array_equal(got[0], want[0])
+
+
+def test_prove_2_22_accepted_by_verifier():
+    """Four times the benchmark's size (the 8n domain has 2^25 points, 37 GiB resident): the proof passes the
+    verifier's equation under the trapdoor and the whole verifier with its pairing (tools/big_proof_check.py; the
+    same script checks 2^24 gates, 147 GiB resident, outside the suite)."""
+    import os
+    import runpy
+    import sys
+    from conftest import ROOT
+    argv = sys.argv
+    sys.argv = ["big_proof_check.py", "22"]
+    try:
+        runpy.run_path(os.path.join(ROOT, "tools", "big_proof_check.py"), run_name="__main__")
+    finally:
+        sys.argv = argv

@@ -205,3 +205,47 @@ def test_prove_2_14(ctx, orc):
     got = gp.prove(c["wires"].reshape(-1, 4), c["public_inputs"], bl)
     for key in ("challenges", "evals", "comms_inf", "comms"):
         assert np.array_equal(got[key], want[key]), key
+
+
+def _with_public_inputs(c, gates, seed):
+    """Turns more gates into public-input gates: q_c[i] -= delta, PI[i] = delta keeps gate i satisfied."""
+    deltas = M.random_fr_ints(len(gates), seed)
+    q_c = M.fr_vec_from_mont(c["selectors"][5])
+    for g, dlt in zip(gates, deltas):
+        q_c[g] = (q_c[g] - dlt) % M.R_MOD
+    c["selectors"][5] = M.fr_vec_to_mont(q_c)
+    c["pi_indexes"] = list(c["pi_indexes"]) + list(gates)
+    c["public_inputs"] = np.concatenate([c["public_inputs"], M.fr_vec_to_mont(deltas)])
+    return c
+
+
+@pytest.mark.parametrize("gates", [[3, 17], [1, 2, 40], [5, 9, 11, 30, 31, 50], [7, 7]])
+def test_prove_several_public_inputs(ctx, orc, srs, gates):
+    """Up to four distinct positions use the key-resident Lagrange vectors, more fall back to the transform; a
+    repeated position keeps the later value, as the reference's dense vector does (composer.rs:1001-1014)."""
+    from zkvm_amd import circuits
+    c = _with_public_inputs(_circuit(orc, 64, seed=len(gates) + 40), gates, seed=9)
+    gp, op = _provers(ctx, orc, srs, c)
+    bl = circuits.random_blinders(3)
+    want = op.prove(c["wires"], c["public_inputs"], bl)
+    if len(set(gates)) == len(gates):
+        assert want["rc"] == 0
+    got = None
+    try:
+        got = gp.prove(c["wires"].reshape(-1, 4), c["public_inputs"], bl)
+    except Exception:
+        assert want["rc"] != 0
+    if got is not None:
+        assert want["rc"] == 0
+        for key in ("challenges", "evals", "comms_inf", "comms"):
+            assert np.array_equal(got[key], want[key]), key
+    # fewer values than positions: the remaining positions stay zero on both sides
+    short = c["public_inputs"][:1]
+    want = op.prove(c["wires"], short, bl)
+    try:
+        got = gp.prove(c["wires"].reshape(-1, 4), short, bl)
+        assert want["rc"] == 0
+        for key in ("challenges", "evals", "comms"):
+            assert np.array_equal(got[key], want[key]), key
+    except Exception:
+        assert want["rc"] != 0

@@ -2,6 +2,7 @@
 #include "prover.hpp"
 #include <map>
 #include "widgets.cuh"
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 
@@ -81,9 +82,12 @@ Prover::~Prover() {
     sigma_.release();
     work_.release();
     small_.release();
+    pi_lagrange_.release();
 }
 
-size_t Prover::device_bytes() const { return polys_.cap + evals_.cap + sigma_.cap + work_.cap + small_.cap; }
+size_t Prover::device_bytes() const {
+    return polys_.cap + evals_.cap + sigma_.cap + work_.cap + small_.cap + pi_lagrange_.cap;
+}
 
 const Fr *Prover::key_eval8n(int k) const { return reinterpret_cast<const Fr *>(evals_.p) + (size_t)k * 8 * n_; }
 
@@ -184,6 +188,31 @@ void Prover::build_l1_and_vanishing(bool with_linear) {
     }
 }
 
+// The public-input polynomial is sum_j pi_j L_j (composer.rs:1001-1014 + prover.rs:305-306); its 8n coset evaluations
+// are what the quotient needs (quotient_poly.rs:46-51).  A circuit has few public inputs at fixed gates, so for up to
+// four of them (and at most 8 GiB) the coset evaluations of their Lagrange polynomials stay resident with the key and a
+// proof forms the combination instead of running an n-point iFFT and an 8n-point coset FFT.
+void Prover::build_pi_lagrange() {
+    pi_lagrange_idx_.clear();
+    std::vector<uint64_t> idx;
+    for (uint64_t i : pi_indexes_)
+        if (i < n_) idx.push_back(i);
+    std::sort(idx.begin(), idx.end());
+    idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+    const size_t N8 = (size_t)8 * n_;
+    if (idx.empty() || idx.size() > 4 || idx.size() * N8 * sizeof(Fr) > (8ull << 30)) return;
+    pi_lagrange_.reserve(idx.size() * N8 * sizeof(Fr));
+    Fr *tmp = work_.as<Fr>();
+    const Fr one = Fr::one();
+    for (size_t j = 0; j < idx.size(); j++) {
+        poly_.zero_and_scatter(tmp, n_, &idx[j], &one, 1);
+        ntt_.transform(NTT_IFFT, tmp, n_, tmp, log_n_);
+        ntt_.transform(NTT_COSET_FFT, tmp, n_, pi_lagrange_.as<Fr>() + j * N8, log_n_ + 3);
+    }
+    ZK_HIP(hipStreamSynchronize(stream_));
+    pi_lagrange_idx_ = idx;
+}
+
 void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector_evals_host, const std::string &label,
                       const uint64_t *pi_indexes, size_t n_pi) {
     ZK_REQUIRE(n >= 1 && (n & (n - 1)) == 0, ZKGPU_ERR_INVALID_ARG, "prover_key_load: n must be a power of two");
@@ -232,6 +261,7 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
             sel_comms_[k] = affine_identity();
         }
     }
+    build_pi_lagrange();
 }
 
 // ---- key (de)serialization --------------------------------------------------------------------------------------
@@ -428,6 +458,7 @@ void Prover::load_key_bytes(const uint8_t *b, size_t len, const uint64_t *pi_ind
         }
     }
     ZK_HIP(hipStreamSynchronize(stream_));
+    build_pi_lagrange();
 }
 
 size_t Prover::to_bytes(uint8_t *out, size_t cap) {
@@ -543,7 +574,7 @@ void Prover::blind_poly(const Fr *evals_dev, int hiding_degree, const Fr *blinde
 }
 
 uint64_t Prover::quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4], const uint64_t wire_len[4], const Fr *pi,
-                          uint64_t pi_len, const Fr ch[7], Fr *t_out) {
+                          uint64_t pi_len, const Fr ch[7], Fr *t_out, const Fr *pi_values) {
     ZK_REQUIRE(loaded(), ZKGPU_ERR_NOT_LOADED, "quotient: no prover key loaded");
     const size_t N8 = (size_t)8 * n_;
     small_.reserve(6 * N8 * sizeof(Fr));
@@ -552,7 +583,22 @@ uint64_t Prover::quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4],
     // quotient_poly.rs:46-51,120
     ntt_.transform(NTT_COSET_FFT, z, z_len, ev, lg8);
     for (int k = 0; k < 4; k++) ntt_.transform(NTT_COSET_FFT, wires[k], wire_len[k], ev + (size_t)(k + 1) * N8, lg8);
-    ntt_.transform(NTT_COSET_FFT, pi, pi_len, ev + 5 * N8, lg8);
+    if (pi != nullptr) {
+        ntt_.transform(NTT_COSET_FFT, pi, pi_len, ev + 5 * N8, lg8);
+    } else {
+        ZK_REQUIRE(pi_values != nullptr && !pi_lagrange_idx_.empty(), ZKGPU_ERR_INTERNAL, "quotient: no public-input vectors");
+        LinArgs L;
+        L.n_terms = (int)pi_lagrange_idx_.size();
+        for (int j = 0; j < L.n_terms; j++) {
+            L.t[j].coeffs = pi_lagrange_.as<Fr>() + (size_t)j * N8;
+            L.t[j].len = N8;
+            L.t[j].scalar = pi_values[j];
+        }
+        L.constant = Fr::zero();
+        L.out = ev + 5 * N8;
+        L.out_len = N8;
+        poly_.linear_combination(L);
+    }
     QuotientArgs q;
     q.z = ev;
     q.a = ev + N8;
@@ -693,6 +739,7 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     const Fr logic_ch = tr.challenge_scalar("logic separation challenge");
     const Fr fixed_ch = tr.challenge_scalar("fixed base separation challenge");
     const Fr var_ch = tr.challenge_scalar("variable base separation challenge");
+    std::vector<Fr> pi_resident;
     {
         // composer.rs:1001-1014 dense public inputs, then ifft (prover.rs:305-306)
         // The dense vector is built on the device from the few (index, value) pairs; a later pair with the same index
@@ -706,12 +753,22 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
             idx.push_back(kv.first);
             vals.push_back(kv.second);
         }
-        poly_.zero_and_scatter(p_pi, n, idx.data(), vals.data(), (uint32_t)idx.size());
-        ntt_.transform(NTT_IFFT, p_pi, n, p_pi, log_n_);
+        if (!pi_lagrange_idx_.empty()) {
+            // the values in the order of the resident Lagrange vectors; positions this proof leaves out are zero
+            pi_resident.assign(pi_lagrange_idx_.size(), Fr::zero());
+            for (size_t j = 0; j < pi_lagrange_idx_.size(); j++) {
+                auto it = last.find(pi_lagrange_idx_[j]);
+                if (it != last.end()) pi_resident[j] = it->second;
+            }
+        } else {
+            poly_.zero_and_scatter(p_pi, n, idx.data(), vals.data(), (uint32_t)idx.size());
+            ntt_.transform(NTT_IFFT, p_pi, n, p_pi, log_n_);
+        }
     }
     const Fr ch7[7] = {alpha, beta, gamma, range_ch, logic_ch, fixed_ch, var_ch};
     const uint64_t wl[4] = {n + 2, n + 2, n + 2, n + 2};
-    const uint64_t t_len = quotient(p_z, n + 3, wp, wl, p_pi, n, ch7, t);
+    const uint64_t t_len = pi_resident.empty() ? quotient(p_z, n + 3, wp, wl, p_pi, n, ch7, t)
+                                               : quotient(p_z, n + 3, wp, wl, nullptr, 0, ch7, t, pi_resident.data());
     lap(2, t_phase);
     // prover.rs:327-351: the reference slices t[3n..] and indexes t_fourth[0]; both panic when t is shorter
     if (t_len < 3 * n + 1) return ZKGPU_ERR_QUOTIENT_SHAPE;

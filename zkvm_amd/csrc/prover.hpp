@@ -59,8 +59,10 @@ class Prover {
 
     // build_quotient_polynomial (quotient_poly.rs:15-100) on device polynomials; t_out must hold 8n elements.
     // Returns the coefficient count after truncating leading zeros.
+    // With pi == nullptr the public-input polynomial on the coset is sum_j pi_values[j] * L_idx(j) over the resident
+    // Lagrange vectors of the key's public-input positions (same values, no transform).
     uint64_t quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4], const uint64_t wire_len[4], const Fr *pi,
-                      uint64_t pi_len, const Fr challenges7[7], Fr *t_out);
+                      uint64_t pi_len, const Fr challenges7[7], Fr *t_out, const Fr *pi_values = nullptr);
 
     // Prover::prove.  wires_host: 4 x n values; blinders: 14 scalars in the reference's draw order.
     // Returns 0 or a ZKGPU_ERR_* code for the reference's error paths.
@@ -75,6 +77,7 @@ class Prover {
     int commit_many(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, AffineOut *out);
     void blind_poly(const Fr *evals_dev, int hiding_degree, const Fr *blinders, Fr *out_dev);
     void build_l1_and_vanishing(bool with_linear);
+    void build_pi_lagrange();
 
     hipStream_t stream_;
     NttEngine &ntt_;
@@ -97,6 +100,8 @@ class Prover {
     DevBuf sigma_;   // 4 x n sigma values (their FFT is what compute_permutation_vec recomputes)
     DevBuf work_;    // per-proof buffers
     DevBuf small_;   // 15 evaluations etc.
+    DevBuf pi_lagrange_;                  // for keys with few public inputs: L_j on the 8n coset, one vector per position
+    std::vector<uint64_t> pi_lagrange_idx_;   // the distinct positions, ascending; empty = not resident
 };
 
 }  // namespace zk

@@ -236,3 +236,34 @@ def test_short_top_window_goes_through_the_task_path(ctx, orc):
     want_xy, want_inf = oracle_affine(orc, pts, sc)
     assert got_inf == want_inf and np.array_equal(got_xy, want_xy)
     assert elapsed < 0.03, elapsed
+
+
+def test_kzg_opening_checked_by_pairing(ctx, orc):
+    """The reference's KZG tests (kzg10/key.rs:341-459) check commit + open with the pairing:
+    e(C - v G, h) = e(W, [tau] h - z h) for W = commit((p - v) / (X - z)).  Commitment, evaluation and the Ruffini
+    quotient come from the GPU, the pairing from the oracle."""
+    import plonk_check
+    from oracle import pairing as Pg
+    from zkvm_amd import api
+    n = 200
+    tau = M.random_fr_mont(1, seed=321)[0]
+    tau_int = M.fr_from_mont(tau)
+    srs, _ = orc.srs_powers(orc.g1_generator(), tau, n)
+    ctx.srs_load(srs)
+    poly = M.random_fr_mont(n, 11)
+    z = M.random_fr_mont(1, 12)[0]
+    c_xy, c_inf = ctx.commit(poly)
+    v = api.poly_eval(ctx, poly, z)
+    w_poly = api.poly_ruffini(ctx, poly, z)          # (p - p(z)) / (X - z): the remainder is dropped
+    w_xy, w_inf = ctx.commit(w_poly)
+    g = M.affine_from_limbs(srs[0])
+    C, W = M.affine_from_limbs(c_xy, c_inf), M.affine_from_limbs(w_xy, w_inf)
+    v_int, z_int = M.fr_from_mont(v), M.fr_from_mont(z)
+    vg = M.ec_mul(g, v_int)
+    lhs = M.ec_add(C, None if vg is None else (vg[0], (-vg[1]) % M.P_MOD))
+    h, tau_h = plonk_check.opening_key_g2(tau_int)
+    rhs_g2 = Pg.g2_add(tau_h, Pg.g2_neg(Pg.g2_mul(h, z_int)))
+    neg_w = (W[0], (-W[1]) % M.P_MOD)
+    assert Pg.pairing_product_is_one([(lhs, h), (neg_w, rhs_g2)])
+    wrong = M.ec_add(lhs, g)
+    assert not Pg.pairing_product_is_one([(wrong, h), (neg_w, rhs_g2)])

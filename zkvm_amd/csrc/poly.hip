@@ -216,6 +216,10 @@ struct OutlinedMul {
 };
 #define FM(a, b) fr_mul_outlined((a), (b))
 
+// WIDGETS = false compiles the arithmetic and permutation terms only (circuits whose range, logic and curve
+// selectors are identically zero): with every widget compiled in, the kernel needs all 256 VGPRs and runs one wave
+// per SIMD, which leaves nothing to hide the latency of its two dozen streams.
+template <bool WIDGETS>
 __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs q) {
     typedef OutlinedMul M;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,7 +236,7 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs q) {
     t = Fr::add(t, ld(q.sel[Q_C] + i));
     t = FM(t, ld(q.sel[Q_ARITH] + i));
 
-    if (q.widgets) {  // every other widget is multiplied by its selector: zero selectors contribute exactly 0
+    if (WIDGETS && q.widgets) {  // every other widget is multiplied by its selector: zero selectors contribute exactly 0
         const Fr a_w = ld(q.a + iw), b_w = ld(q.b + iw), d_w = ld(q.d + iw);
         if (q.widgets & 1u) {  // range/proverkey.rs:31-59
             Fr s = w_range_identity<M>(q.range_ch, a, b, c, d, d_w);
@@ -277,7 +281,10 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs q) {
 
 void PolyEngine::quotient(const QuotientArgs &args) {
     ZK_REQUIRE(args.n8 >= 8 && (args.n8 & (args.n8 - 1)) == 0, ZKGPU_ERR_INVALID_ARG, "quotient: 8n must be a power of two");
-    hipLaunchKernelGGL(quotient_kernel, dim3(ceil_div(args.n8, 256)), dim3(256), 0, stream_, args);
+    if (args.widgets)
+        hipLaunchKernelGGL(quotient_kernel<true>, dim3(ceil_div(args.n8, 256)), dim3(256), 0, stream_, args);
+    else
+        hipLaunchKernelGGL(quotient_kernel<false>, dim3(ceil_div(args.n8, 256)), dim3(256), 0, stream_, args);
     ZK_HIP(hipGetLastError());
 }
 

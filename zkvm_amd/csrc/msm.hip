@@ -303,8 +303,9 @@ __global__ void __launch_bounds__(1024) msm_sort2_kernel(const uint32_t *mid_key
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t j = j0 + u * blockDim.x;
-            kk[u] = j < hi ? mid_key[j] : 0xffffffffu;
-            if (PASS) vv[u] = j < hi ? mid_val[j] : 0u;
+            // read once: streaming loads keep these lists from evicting the half-filled output lines of the scatter
+            kk[u] = j < hi ? __builtin_nontemporal_load(mid_key + j) : 0xffffffffu;
+            if (PASS) vv[u] = j < hi ? __builtin_nontemporal_load(mid_val + j) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {

@@ -286,15 +286,13 @@ def cpu_baseline_msm():
 PROVE_LOG = 20
 
 
-def tiled_srs(n_points, device=None):
-    """SRS-shaped point table: 2^12 consecutive multiples of G from the oracle, tiled (duplicates do not change the
-    work: the addition formulas are complete and the bucket method never compares points)."""
+def tiled_srs(n_points):
+    """Point table for the CPU baseline only: 2^12 consecutive multiples of G from the oracle, tiled (duplicates do
+    not change the CPU's work: its addition formulas are complete and the bucket method never compares points)."""
     from oracle import pyoracle as orc
     base, _ = orc.g1_multiples_of_generator(1, 1 << 12)
     reps = (n_points + (1 << 12) - 1) >> 12
-    if device is None:
-        return np.tile(base, (reps, 1))[:n_points]
-    return to_dev(base, device).repeat(reps, 1)[:n_points].contiguous()
+    return np.tile(base, (reps, 1))[:n_points]
 
 
 def run_prove(args, rank, world, local, device):

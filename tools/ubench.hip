@@ -54,6 +54,17 @@ static const int ITERS = 4096;
 #define OP_FMA32(k) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a##k) : "v"(m));
 #define OP_MAD32(k) asm volatile("v_mad_u32_u24 %0, %0, %1, %0\n\tv_mul_hi_u32_u24 %0, %0, %1" : "+v"(a##k) : "v"(m));
 
+#define OP_SHR64(k) asm volatile("v_lshrrev_b64 %0, 28, %0" : "+v"(q##k));
+#define OP_AND(k) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a##k) : "v"(m));
+#define OP_ALIGN(k) asm volatile("v_alignbit_b32 %0, %0, %1, 28" : "+v"(a##k) : "v"(m));
+#define OP_SHR32(k) asm volatile("v_lshrrev_b32 %0, 28, %0" : "+v"(a##k));
+#define OP_ADD3(k) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a##k) : "v"(m));
+
+RATE_KERNEL(k_shr64, X8(OP_SHR64))
+RATE_KERNEL(k_and, X8(OP_AND))
+RATE_KERNEL(k_align, X8(OP_ALIGN))
+RATE_KERNEL(k_shr32, X8(OP_SHR32))
+RATE_KERNEL(k_add3, X8(OP_ADD3))
 RATE_KERNEL(k_mad64, X8(OP_MAD64))
 RATE_KERNEL(k_mullo, X8(OP_MULLO))
 RATE_KERNEL(k_mulhi, X8(OP_MULHI))
@@ -152,6 +163,11 @@ int main() {
         if (run_rate("mul_lo", k_mullo, w)) return 1;
         if (run_rate("mul_hi", k_mulhi, w)) return 1;
         if (run_rate("mad_u64", k_mad64, w)) return 1;
+        if (run_rate("lshr_b64", k_shr64, w)) return 1;
+        if (run_rate("and_b32", k_and, w)) return 1;
+        if (run_rate("alignbit", k_align, w)) return 1;
+        if (run_rate("lshr_b32", k_shr32, w)) return 1;
+        if (run_rate("add3_u32", k_add3, w)) return 1;
         if (run_rate("fma_f64", k_fma64, w)) return 1;
     }
     for (int tpb : {256, 512, 1024}) {

@@ -8,16 +8,17 @@
 //   1. digits    every scalar leaves Montgomery form and is cut into K signed digits (|digit| <= 2^(c-1));
 //   2. sort      counting sort of the n*K (entry, bucket) pairs with per-workgroup histograms in LDS (no global
 //                atomics): count pass, exclusive scan = bucket start offsets, scatter pass writing table indices
-//                (with the digit's sign in bit 31) bucket by bucket; oversized buckets are cut into fixed-size
-//                tasks so that no thread ever owns more than BIG_BUCKET additions;
-//   3. schedule  buckets are ordered by decreasing size so that the lanes of a wave carry equal work;
-//   4. accumulate one thread per bucket adds its entries with the complete mixed addition; oversized
-//                buckets are summed by whole workgroups (strided partial sums + LDS tree);
+//                (with the digit's sign in bit 31) bucket by bucket.  More than 2^15 buckets are first partitioned
+//                into ranges of 2^13, and the workgroups of a range are kept on one XCD while they scatter;
+//   3. schedule  buckets are ordered by decreasing size so that the lanes of a wave carry equal work; buckets far
+//                above the expected size are cut into fixed-size tasks for whole workgroups;
+//   4. accumulate one thread per bucket adds its entries with the extended-Jacobian mixed addition on 28-bit limbs
+//                (fq28.cuh); oversized buckets are summed by workgroups (strided partial sums + LDS tree);
 //   5. reduce    sum_b (b+1) * bucket_b: running sums over segments of L buckets give per-segment totals T_s and
 //                local weighted sums W_s; sum_s s*T_s is then taken bit by bit (Q_k = sum of the T_s whose index
-//                has bit k set), every sum a wide tree, because an EC addition has ~30 us of latency at low
-//                occupancy and depth, not work, is what this phase costs;
+//                has bit k set), every sum a wide tree;
 //   6. the few group sums return to the host: total = sum W + L * sum_k 2^k Q_k + sum T, then to affine.
+// Up to MAX_BATCH sums over the same table run as one batch and share the sort and reduction launches.
 // The reference's unsigned digits, window size and special cases for 0 and 1
 // (multiscalar_mul.rs:150-195) change only the order of group additions; the sum, and so the affine
 // commitment compared by the tests, is the same group element.
@@ -29,8 +30,8 @@
 
 namespace zk {
 
-static const uint32_t BIG_BUCKET = 256;   // size classes of the schedule; buckets above BIG_BUCKET << shift entries are
-                                          // processed by workgroups (shift grows with the mean bucket size)
+static const uint32_t BIG_BUCKET = 256;   // number of size classes of the schedule (count >> shift, shift grows with the
+                                          // mean bucket size); also the floor of the model's oversize allowance
 static const uint32_t BIG_CHUNK = 4096;   // entries per workgroup task
 static const uint32_t SCAN_ITEMS = 1024;  // histogram entries scanned per block
 

@@ -15,6 +15,8 @@
 //   * coset_fft  = inputs j < len_in multiplied by g^j while they are loaded (domain.rs:176-185: the powers
 //                  are distributed over the un-padded coefficients), then the forward network.
 // HBM traffic per pass is one read and one write of the vector plus the pass's share of the twiddle table.
+// Inside a pass the tile is held as 9 limbs of 29 bits with lazy reduction (see "tile arithmetic" below); the
+// kernel is bound by integer VALU issue, not by memory.
 #include "ntt.hpp"
 
 namespace zk {

@@ -1,0 +1,107 @@
+"""The Composer mirror (zkvm_amd/composer.py) end to end, the way the reference tests its circuits
+(coset-poseidon/src/hades/permutation/gadget.rs:199-277: compile, prove, verify, and a must-fail case): tables from
+the composer, proof from the CPU oracle, acceptance by the verifier restatement with its pairing."""
+import numpy as np
+import pytest
+
+import model as M
+
+R = M.R_MOD
+
+
+def cubic_circuit(x, claimed=None, bit=1):
+    """x^3 + x + 5 = y with y public, a boolean and a select on the side."""
+    from zkvm_amd.composer import Composer, Constraint
+    c = Composer.initialized()
+    y = (x ** 3 + x + 5) % R if claimed is None else claimed
+    wx = c.append_witness(x)
+    x2 = c.gate_mul(Constraint().mult(1).a(wx).b(wx))
+    x3 = c.gate_mul(Constraint().mult(1).a(x2).b(wx))
+    s = c.gate_add(Constraint().left(1).right(1).constant(5).a(x3).b(wx))
+    wy = c.append_public(y)
+    c.assert_equal(s, wy)
+    wb = c.append_witness(bit)
+    c.component_boolean(wb)
+    sel = c.component_select(wb, wx, x2)
+    c.assert_equal(sel, wx if bit == 1 else x2)
+    one = c.component_select_one(wb, wx)
+    c.assert_equal_constant(c.component_select_zero(wb, one), (x if bit else 0))
+    k = c.append_constant(77)
+    c.assert_equal(k, c.append_constant(77))
+    return c
+
+
+def _oracle_prover(orc, circ, label=b"composer"):
+    circ["selectors"][11:15] = np.stack([orc.sigma_to_lagrange(circ["sigma_map"][k]) for k in range(4)])
+    tau = M.random_fr_mont(1, seed=5151)[0]
+    srs, _ = orc.srs_powers(orc.g1_generator(), tau, circ["n"] + 7)
+    op = orc.Prover(circ["n"], circ["constraints"], circ["selectors"], srs, label, circ["pi_indexes"])
+    assert op.preprocess_rc == 0
+    return op, srs, M.fr_from_mont(tau)
+
+
+def test_initialized_composer_matches_the_reference_layout():
+    """composer.rs:139-195: witnesses 0 and 1, two constant gates, two dummy gates that are satisfied"""
+    from zkvm_amd.composer import Composer
+    c = Composer.initialized()
+    assert c.constraints() == 4 and c.witnesses[:2] == [0, 1]
+    for coeff, w in c.gates:
+        a, b, o, d = (c.witnesses[i] for i in w)
+        assert (coeff["q_m"] * a * b + coeff["q_l"] * a + coeff["q_r"] * b + coeff["q_o"] * o + coeff["q_f"] * d
+                + coeff["q_c"]) % R == 0
+    t = c.tables()
+    assert t["n"] == 4 and t["pi_indexes"] == []
+    # copy constraints: every witness used twice sits on one cycle
+    assert sorted(t["sigma_map"].reshape(-1).tolist()) == list(range(16))
+
+
+@pytest.mark.parametrize("bit", [0, 1])
+def test_circuit_proves_and_verifies(orc, bit):
+    from zkvm_amd import circuits
+    import plonk_check
+    comp = cubic_circuit(3, bit=bit)
+    circ = comp.tables()
+    assert circ["public_inputs"].shape[0] == 1 and M.fr_from_mont(circ["public_inputs"][0]) == 35
+    # every gate holds and every copy cycle carries one value
+    flat = np.concatenate([circ["wires"][k] for k in range(4)])
+    sm = circ["sigma_map"].reshape(-1)
+    assert np.array_equal(flat, flat[sm])
+    op, srs, tau = _oracle_prover(orc, circ)
+    proof = op.prove(circ["wires"], circ["public_inputs"], circuits.random_blinders(1))
+    assert proof["rc"] == 0
+    sxy, sinf = op.selector_comms()
+    h, tau_h = plonk_check.opening_key_g2(tau)
+    args = (sxy, sinf, circ["public_inputs"], circ["pi_indexes"], srs[0], h, tau_h, orc)
+    assert plonk_check.verify(circ["n"], circ["constraints"], b"composer", proof, *args)
+    wrong = M.fr_vec_to_mont([36])
+    assert not plonk_check.verify(circ["n"], circ["constraints"], b"composer", proof, sxy, sinf, wrong, circ["pi_indexes"],
+                                  srs[0], h, tau_h, orc)
+
+
+def test_false_statement_cannot_be_proved(orc):
+    """The must-fail case: with a wrong claimed output the quotient is no polynomial and the commitment of its
+    fourth part fails (PolynomialDegreeTooLarge), as in the reference's hades gadget test."""
+    from zkvm_amd import circuits
+    circ = cubic_circuit(3, claimed=36).tables()
+    op, _, _ = _oracle_prover(orc, circ)
+    assert op.prove(circ["wires"], circ["public_inputs"], circuits.random_blinders(2))["rc"] == 2
+
+
+@pytest.mark.gpu
+def test_gpu_proof_of_a_composed_circuit(orc):
+    import zkvm_amd
+    from zkvm_amd import api, circuits
+    circ = cubic_circuit(12345, bit=1).tables()
+    op, srs, _ = _oracle_prover(orc, circ)
+    ctx = zkvm_amd.Context(0)
+    try:
+        ctx.srs_load(srs)
+        gp = api.Prover(ctx, circ["n"], circ["constraints"], circ["selectors"].reshape(-1, 4), b"composer", circ["pi_indexes"])
+        bl = circuits.random_blinders(3)
+        want = op.prove(circ["wires"], circ["public_inputs"], bl)
+        got = gp.prove(circ["wires"].reshape(-1, 4), circ["public_inputs"], bl)
+        assert want["rc"] == 0
+        for key in ("challenges", "evals", "comms_inf", "comms"):
+            assert np.array_equal(got[key], want[key]), key
+    finally:
+        ctx.close()

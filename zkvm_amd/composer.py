@@ -1,0 +1,235 @@
+"""Host-side mirror of the arithmetic part of the reference's circuit front-end: `Constraint`
+(plonk/src/composer/constraint_system/constraint.rs) and `Composer` (plonk/src/composer.rs) with the gates the
+Poseidon-Merkle opening circuit uses (poseidon-merkle/src/zk.rs:16-102: gate_add, gate_mul, assert_equal,
+component_boolean, component_select, constants and public inputs), and the copy-constraint bookkeeping of
+`Permutation` (plonk/src/composer/permutation.rs:30-109).  It produces exactly the tables the prover consumes:
+15 selector rows, the sigma map, the four witness columns and the public-input positions.
+
+Range, logic and curve gates are not mirrored: append_custom_gate accepts their selectors, the component_* helpers
+that build them are absent.  Values are canonical integers modulo r; tables come out as Montgomery limbs.
+"""
+import numpy as np
+
+from . import circuits
+
+R = circuits.R_MOD
+
+_COEFFS = ("q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "pi", "q_arith", "q_range", "q_logic", "q_fixed_group_add",
+           "q_variable_group_add")
+_EXTERNAL = _COEFFS[:7]          # what Constraint::from_external keeps (constraint.rs:90-104)
+
+
+class Constraint:
+    """constraint.rs:76-216: twelve coefficients, four wired witnesses (all Composer.ZERO by default)."""
+
+    def __init__(self):
+        self.coeff = dict.fromkeys(_COEFFS, 0)
+        self.w = [0, 0, 0, 0]          # a b c d
+        self.has_public_input = False
+
+    def _copy(self):
+        c = Constraint()
+        c.coeff = dict(self.coeff)
+        c.w = list(self.w)
+        c.has_public_input = self.has_public_input
+        return c
+
+    def _set(self, name, value):
+        c = self._copy()
+        c.coeff[name] = int(value) % R
+        return c
+
+    def mult(self, s):
+        return self._set("q_m", s)
+
+    def left(self, s):
+        return self._set("q_l", s)
+
+    def right(self, s):
+        return self._set("q_r", s)
+
+    def output(self, s):
+        return self._set("q_o", s)
+
+    def fourth(self, s):
+        return self._set("q_f", s)
+
+    def constant(self, s):
+        return self._set("q_c", s)
+
+    def public(self, s):
+        c = self._set("pi", s)
+        c.has_public_input = True
+        return c
+
+    def _wire(self, k, witness):
+        c = self._copy()
+        c.w[k] = int(witness)
+        return c
+
+    def a(self, w):
+        return self._wire(0, w)
+
+    def b(self, w):
+        return self._wire(1, w)
+
+    def c(self, w):
+        return self._wire(2, w)
+
+    def d(self, w):
+        return self._wire(3, w)
+
+    @staticmethod
+    def arithmetic(s):
+        """constraint.rs:181-183: the external coefficients and witnesses, q_arith = 1"""
+        c = Constraint()
+        for name in _EXTERNAL:
+            c.coeff[name] = s.coeff[name]
+        c.w = list(s.w)
+        c.has_public_input = s.has_public_input
+        c.coeff["q_arith"] = 1
+        return c
+
+
+class Composer:
+    """composer.rs:36-1015 (arithmetic subset).  Witnesses are indexes into `witnesses`."""
+    ZERO, ONE = 0, 1
+
+    def __init__(self):               # Composer::uninitialized, composer.rs:154-162
+        self.gates = []               # (coefficients dict, [a, b, c, d])
+        self.public_inputs = {}       # gate index -> value
+        self.witnesses = []
+        self.wire_map = []            # per witness: list of (column, gate index), composer/permutation.rs:45-76
+
+    @classmethod
+    def initialized(cls):
+        """composer.rs:139-195: the constants 0 and 1 and the two dummy gates"""
+        c = cls()
+        zero = c.append_witness(0)
+        one = c.append_witness(1)
+        c.assert_equal_constant(zero, 0)
+        c.assert_equal_constant(one, 1)
+        six, one_b, seven, min_twenty = (c.append_witness(v) for v in (6, 1, 7, -20))
+        c.append_gate(Constraint().mult(1).left(2).right(3).fourth(1).constant(4).output(4)
+                      .a(six).b(seven).d(one_b).c(min_twenty))
+        c.append_gate(Constraint().mult(1).left(1).right(1).constant(127).output(1).a(min_twenty).b(six).c(seven))
+        return c
+
+    def __getitem__(self, witness):
+        return self.witnesses[witness]
+
+    def constraints(self):
+        return len(self.gates)
+
+    def append_witness(self, value):
+        self.witnesses.append(int(value) % R)
+        self.wire_map.append([])
+        return len(self.witnesses) - 1
+
+    def append_custom_gate(self, constraint):
+        """composer.rs:76-131"""
+        index = len(self.gates)
+        self.gates.append((dict(constraint.coeff), list(constraint.w)))
+        if constraint.has_public_input:
+            self.public_inputs[index] = constraint.coeff["pi"]
+        for column, witness in enumerate(constraint.w):
+            self.wire_map[witness].append((column, index))
+
+    def append_gate(self, constraint):
+        self.append_custom_gate(Constraint.arithmetic(constraint))
+
+    def append_evaluated_output(self, s):
+        """composer.rs:451-501: the output witness that satisfies the gate, or None when q_o = 0"""
+        a, b, d = (self.witnesses[s.w[k]] for k in (0, 1, 3))
+        k = s.coeff
+        value = (k["q_m"] * a * b + k["q_l"] * a + k["q_r"] * b + k["q_f"] * d + k["q_c"] + k["pi"]) % R
+        if k["q_o"] == 0:
+            return None
+        return self.append_witness(value * (-pow(k["q_o"], -1, R)) % R)
+
+    def append_constant(self, constant):
+        w = self.append_witness(constant)
+        self.assert_equal_constant(w, constant)
+        return w
+
+    def append_public(self, public):
+        """composer.rs:561-572"""
+        w = self.append_witness(public)
+        self.append_gate(Constraint().left(-1).a(w).public(public))
+        return w
+
+    def assert_equal(self, left, right):
+        self.append_gate(Constraint().left(1).right(-1).a(left).b(right))
+
+    def assert_equal_constant(self, witness, constant, public=None):
+        c = Constraint().left(-1).a(witness).constant(constant)
+        if public is not None:
+            c = c.public(public)
+        self.append_gate(c)
+
+    def component_boolean(self, witness):
+        """composer.rs:705-716: w * w - w = 0"""
+        self.append_gate(Constraint().mult(1).output(-1).a(witness).b(witness).c(witness).d(self.ZERO))
+
+    def gate_add(self, constraint):
+        """composer.rs:936-948"""
+        c = Constraint.arithmetic(constraint).output(-1)
+        out = self.append_evaluated_output(c)
+        self.append_gate(c.c(out))
+        return out
+
+    gate_mul = gate_add               # composer.rs:950-962: the same body
+
+    def component_select(self, bit, a, b):
+        """composer.rs:781-803: bit ? a : b"""
+        bit_times_a = self.gate_mul(Constraint().mult(1).a(bit).b(a))
+        one_min_bit = self.gate_add(Constraint().left(-1).constant(1).a(bit))
+        one_min_bit_b = self.gate_mul(Constraint().mult(1).a(one_min_bit).b(b))
+        return self.gate_add(Constraint().left(1).right(1).a(one_min_bit_b).b(bit_times_a))
+
+    def component_select_one(self, bit, value):
+        """composer.rs:805-829: bit ? value : 1"""
+        out = self.append_witness(1 - self[bit] + self[bit] * self[value])
+        self.append_gate(Constraint().mult(1).left(-1).output(-1).constant(1).a(bit).b(value).c(out))
+        return out
+
+    def component_select_zero(self, bit, value):
+        return self.gate_mul(Constraint().mult(1).a(bit).b(value))
+
+    def public_input_indexes(self):
+        return sorted(self.public_inputs)
+
+    def public_input_values(self):
+        return [self.public_inputs[i] for i in self.public_input_indexes()]
+
+    # ---- what Compiler::preprocess and Prover::prove read off the composer ---------------------------------
+    def size(self):
+        """compiler.rs:86-87: constraints.next_power_of_two()"""
+        n = 1
+        while n < len(self.gates):
+            n <<= 1
+        return n
+
+    def tables(self):
+        """-> circuit dict in the layout of zkvm_amd.circuits: selectors (15, n, 4) with empty sigma rows
+        (compiler.rs:96-121), sigma_map (4, n) with entry = column * n + gate (compute_sigma_permutations,
+        composer/permutation.rs:78-109), wires (4, n, 4) zero-padded (prover.rs:226-238), public inputs."""
+        n = self.size()
+        sel = np.zeros((15, n, 4), dtype=np.uint64)
+        names = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic", "q_fixed_group_add",
+                 "q_variable_group_add"]
+        for row, name in enumerate(names):
+            vals = [circuits.to_mont(g[0][name]) for g in self.gates] + [0] * (n - len(self.gates))
+            sel[row] = circuits.ints_to_limbs(vals)
+        sigma = np.arange(4 * n, dtype=np.uint64).reshape(4, n)
+        for wires in self.wire_map:
+            for k, (column, gate) in enumerate(wires):
+                nxt_column, nxt_gate = wires[(k + 1) % len(wires)]
+                sigma[column, gate] = nxt_column * n + nxt_gate
+        cols = []
+        for column in range(4):
+            vals = [circuits.to_mont(self.witnesses[g[1][column]]) for g in self.gates] + [0] * (n - len(self.gates))
+            cols.append(circuits.ints_to_limbs(vals))
+        pis = circuits.ints_to_limbs([circuits.to_mont(v) for v in self.public_input_values()])
+        return dict(n=n, constraints=len(self.gates), selectors=sel, sigma_map=sigma, wires=np.stack(cols),
+                    public_inputs=pis.reshape(-1, 4), pi_indexes=self.public_input_indexes())

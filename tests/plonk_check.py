@@ -84,8 +84,28 @@ def pairing_points(n, proof, sel_xy, sel_inf, public_inputs, g_xy, u, tamper=0):
     qa = e["q_arith_eval"]
     terms = [(e["a_eval"] * e["b_eval"] * qa, vk["q_m"]), (e["a_eval"] * qa, vk["q_l"]), (e["b_eval"] * qa, vk["q_r"]),
              (e["c_eval"] * qa, vk["q_o"]), (e["d_eval"] * qa, vk["q_f"]), (qa, vk["q_c"])]
-    for name in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add"):
-        assert vk[name] is None
+    for name in ("q_fixed_group_add", "q_variable_group_add"):
+        assert vk[name] is None             # curve gates: not covered by this restatement
+    _, _, _, range_ch, logic_ch = _ints(proof["challenges"])[:5]
+
+    def delta(f):                           # range/proverkey.rs:92-97
+        return f * (f - 1) * (f - 2) * (f - 3) % R
+
+    if vk["q_range"] is not None:           # widget/range/verifierkey.rs:38-62
+        k1 = range_ch * range_ch % R
+        b_sum = (delta(e["c_eval"] - 4 * e["d_eval"]) + delta(e["b_eval"] - 4 * e["c_eval"]) * k1
+                 + delta(e["a_eval"] - 4 * e["b_eval"]) * k1 * k1 + delta(e["d_w_eval"] - 4 * e["a_eval"]) * k1 ** 3) % R
+        terms.append((b_sum * range_ch % R, vk["q_range"]))
+    if vk["q_logic"] is not None:           # widget/logic/verifierkey.rs:38-84, logic/proverkey.rs:132-155
+        k1 = logic_ch * logic_ch % R
+        ai = (e["a_w_eval"] - 4 * e["a_eval"]) % R
+        bi = (e["b_w_eval"] - 4 * e["b_eval"]) % R
+        di = (e["d_w_eval"] - 4 * e["d_eval"]) % R
+        w = e["c_eval"]
+        f_term = w * (w * (4 * w - 18 * (ai + bi) + 81) + 18 * (ai * ai + bi * bi) - 81 * (ai + bi) + 83) % R
+        xor_and = (e["q_c_eval"] * (9 * di - 3 * (ai + bi)) + 3 * (ai + bi + di) - 2 * f_term) % R
+        c_sum = (delta(ai) + delta(bi) * k1 + delta(di) * k1 * k1 + (w - ai * bi) * k1 ** 3 + xor_and * k1 ** 4) % R
+        terms.append((c_sum * logic_ch % R, vk["q_logic"]))
     ident = (e["a_eval"] + beta * z + gamma) * (e["b_eval"] + beta * K[1] * z + gamma) \
         * (e["c_eval"] + beta * K[2] * z + gamma) * (e["d_eval"] + beta * K[3] * z + gamma) * alpha % R
     terms.append(((ident + l1 * alpha * alpha + u) % R, comm["z_comm"]))

@@ -5,8 +5,9 @@ component_boolean, component_select, constants and public inputs), and the copy-
 `Permutation` (plonk/src/composer/permutation.rs:30-109).  It produces exactly the tables the prover consumes:
 15 selector rows, the sigma map, the four witness columns and the public-input positions.
 
-Range, logic and curve gates are not mirrored: append_custom_gate accepts their selectors, the component_* helpers
-that build them are absent.  Values are canonical integers modulo r; tables come out as Montgomery limbs.
+The range and logic components (composer.rs:224-313, 855-934) are mirrored as well, so that circuits exercising the
+prover's range and logic widgets can be built; the curve components (fixed- and variable-base scalar multiplication)
+are not.  Values are canonical integers modulo r; tables come out as Montgomery limbs.
 """
 import numpy as np
 
@@ -88,6 +89,35 @@ class Constraint:
         c.w = list(s.w)
         c.has_public_input = s.has_public_input
         c.coeff["q_arith"] = 1
+        return c
+
+    @staticmethod
+    def _external(s):
+        c = Constraint.arithmetic(s)
+        c.coeff["q_arith"] = 0
+        return c
+
+    @staticmethod
+    def range(s):
+        """constraint.rs:187-189"""
+        c = Constraint._external(s)
+        c.coeff["q_range"] = 1
+        return c
+
+    @staticmethod
+    def logic(s):
+        """constraint.rs:193-197: AND rows carry q_c = q_logic = 1"""
+        c = Constraint._external(s)
+        c.coeff["q_c"] = 1
+        c.coeff["q_logic"] = 1
+        return c
+
+    @staticmethod
+    def logic_xor(s):
+        """constraint.rs:201-205: XOR rows carry q_c = q_logic = -1"""
+        c = Constraint._external(s)
+        c.coeff["q_c"] = R - 1
+        c.coeff["q_logic"] = R - 1
         return c
 
 
@@ -195,6 +225,63 @@ class Composer:
 
     def component_select_zero(self, bit, value):
         return self.gate_mul(Constraint().mult(1).a(bit).b(value))
+
+    def component_range(self, witness, bit_pairs):
+        """composer.rs:855-934: witness < 2^(2 * bit_pairs) through base-4 accumulators, four per range gate"""
+        num_bits = min(bit_pairs * 2, 256)
+        if num_bits == 0:
+            self.append_gate(Constraint().left(1).a(witness))
+            return
+        value = self.witnesses[witness]
+        bits = [(value >> i) & 1 for i in range(256)]        # least significant first
+        num_gates = (num_bits + 7) >> 3
+        num_quads = num_gates * 4
+        pad = 1 + (((num_quads << 1) - num_bits) >> 1)
+        rows = [Constraint.range(Constraint()) for _ in range(num_gates + 1)]
+        accumulators = []
+        acc = 0
+        for i in range(pad, num_quads + 1):
+            bit_index = (num_quads - i) << 1
+            acc = (4 * acc + bits[bit_index] + 2 * bits[bit_index + 1]) % R
+            var = self.append_witness(acc)
+            accumulators.append(var)
+            rows[i // 4].w[(3, 2, 1, 0)[i % 4]] = var        # i % 4: 0 -> d, 1 -> c, 2 -> b, 3 -> a
+        rows[-1] = Constraint()
+        if accumulators:
+            rows[-1].w[3] = accumulators[-1]
+        for row in rows:
+            self.append_custom_gate(row)
+        if accumulators:
+            self.assert_equal(accumulators[-1], witness)
+
+    def append_logic_component(self, a, b, bit_pairs, is_xor):
+        """composer.rs:224-313: the AND / XOR of the low 2 * bit_pairs bits of a and b, one quad per logic gate"""
+        num_bits = min(bit_pairs * 2, 256)
+        num_quads = num_bits >> 1
+        va, vb = self.witnesses[a], self.witnesses[b]
+        a_bits = [(va >> (num_bits - 1 - i)) & 1 for i in range(num_bits)]   # most significant of the window first
+        b_bits = [(vb >> (num_bits - 1 - i)) & 1 for i in range(num_bits)]
+        left_acc = right_acc = out_acc = 0
+        row = Constraint.logic_xor(Constraint()) if is_xor else Constraint.logic(Constraint())
+        for i in range(num_quads):
+            lq = 2 * a_bits[2 * i] + a_bits[2 * i + 1]
+            rq = 2 * b_bits[2 * i] + b_bits[2 * i + 1]
+            oq = (lq ^ rq) if is_xor else (lq & rq)
+            left_acc = (4 * left_acc + lq) % R
+            right_acc = (4 * right_acc + rq) % R
+            out_acc = (4 * out_acc + oq) % R
+            wa, wb, wc, wd = (self.append_witness(v) for v in (left_acc, right_acc, lq * rq, out_acc))
+            row = row.c(wc)
+            self.append_custom_gate(row)
+            row = row.a(wa).b(wb).d(wd)
+        self.append_custom_gate(Constraint().a(row.w[0]).b(row.w[1]).d(row.w[3]))
+        return row.w[3]
+
+    def append_logic_and(self, a, b, bit_pairs):
+        return self.append_logic_component(a, b, bit_pairs, False)
+
+    def append_logic_xor(self, a, b, bit_pairs):
+        return self.append_logic_component(a, b, bit_pairs, True)
 
     def public_input_indexes(self):
         return sorted(self.public_inputs)

@@ -84,9 +84,30 @@ def pairing_points(n, proof, sel_xy, sel_inf, public_inputs, g_xy, u, tamper=0):
     qa = e["q_arith_eval"]
     terms = [(e["a_eval"] * e["b_eval"] * qa, vk["q_m"]), (e["a_eval"] * qa, vk["q_l"]), (e["b_eval"] * qa, vk["q_r"]),
              (e["c_eval"] * qa, vk["q_o"]), (e["d_eval"] * qa, vk["q_f"]), (qa, vk["q_c"])]
-    for name in ("q_fixed_group_add", "q_variable_group_add"):
-        assert vk[name] is None             # curve gates: not covered by this restatement
-    _, _, _, range_ch, logic_ch = _ints(proof["challenges"])[:5]
+    _, _, _, range_ch, logic_ch, fixed_ch, var_ch = _ints(proof["challenges"])[:7]
+    edwards_d = (-10240 * pow(10241, -1, R)) % R         # coset-jubjub/src/lib.rs:368-373
+    if vk["q_fixed_group_add"] is not None:  # widget/ecc/scalar_mul/fixed_base/verifierkey.rs:45-99
+        k1 = fixed_ch * fixed_ch % R
+        acc_x, acc_x_w, acc_y, acc_y_w = e["a_eval"], e["a_w_eval"], e["b_eval"], e["b_w_eval"]
+        xy_alpha = e["c_eval"]
+        bit = (e["d_w_eval"] - 2 * e["d_eval"]) % R
+        bit_consistency = bit * (bit - 1) * (bit + 1) % R
+        y_alpha = (bit * bit * (e["q_r_eval"] - 1) + 1) % R
+        x_alpha = e["q_l_eval"] * bit % R
+        xy_cons = (bit * e["q_c_eval"] - xy_alpha) * k1 % R
+        curve = xy_alpha * acc_x % R * acc_y % R * edwards_d % R
+        x_cons = (acc_x_w + acc_x_w * curve - (x_alpha * acc_y + y_alpha * acc_x)) * k1 * k1 % R
+        y_cons = (acc_y_w - acc_y_w * curve - (x_alpha * acc_x + y_alpha * acc_y)) * k1 ** 3 % R
+        terms.append(((bit_consistency + x_cons + y_cons + xy_cons) * fixed_ch % R, vk["q_fixed_group_add"]))
+    if vk["q_variable_group_add"] is not None:   # widget/ecc/curve_addition/verifierkey.rs:38-80
+        k1 = var_ch * var_ch % R
+        x1, x3, y1, y3, x2, y2, x1y2 = (e["a_eval"], e["a_w_eval"], e["b_eval"], e["b_w_eval"], e["c_eval"], e["d_eval"],
+                                        e["d_w_eval"])
+        y1x2 = y1 * x2 % R
+        xy_cons = (x1 * y2 - x1y2) % R
+        x3_cons = (x1y2 + y1x2 - (x3 + x3 * (edwards_d * x1y2 % R * y1x2 % R))) * k1 % R
+        y3_cons = (y1 * y2 + x1 * x2 - (y3 - y3 * edwards_d % R * x1y2 % R * y1x2)) * k1 * k1 % R
+        terms.append(((xy_cons + x3_cons + y3_cons) * var_ch % R, vk["q_variable_group_add"]))
 
     def delta(f):                           # range/proverkey.rs:92-97
         return f * (f - 1) * (f - 2) * (f - 3) % R

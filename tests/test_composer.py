@@ -173,3 +173,73 @@ def test_gpu_proof_with_range_and_logic_widgets(orc):
             assert np.array_equal(got[key], want[key]), key
     finally:
         ctx.close()
+
+
+def curve_circuit(scalar=0x1234567890abcdef1234567, wrong=False):
+    """[scalar] G by the fixed-base component, plus G + [scalar] G by the curve-addition gate, both exposed."""
+    from zkvm_amd import composer as C
+    c = C.Composer.initialized()
+    k = c.append_witness(scalar)
+    p = c.component_mul_generator(k)
+    want = C.jubjub_mul(C.JUBJUB_GENERATOR, scalar)
+    assert (c[p[0]], c[p[1]]) == want
+    g = c.append_point(C.JUBJUB_GENERATOR)
+    s = c.component_add_point(g, p)
+    total = C.jubjub_add(C.JUBJUB_GENERATOR, want)
+    assert (c[s[0]], c[s[1]]) == total == C.jubjub_mul(C.JUBJUB_GENERATOR, scalar + 1)
+    if wrong:
+        total = C.jubjub_add(total, C.JUBJUB_GENERATOR)
+    c.assert_equal_public_point(s, total)
+    return c
+
+
+def test_jubjub_helpers():
+    from zkvm_amd import composer as C
+    g = C.JUBJUB_GENERATOR
+    on_curve = lambda p: (-p[0] * p[0] + p[1] * p[1] - 1 - C.EDWARDS_D * p[0] * p[0] * p[1] * p[1]) % R == 0
+    assert on_curve(g) and on_curve(C.jubjub_mul(g, 12345))
+    assert C.jubjub_mul(g, C.JUBJUB_SCALAR_MODULUS) == C.JUBJUB_IDENTITY          # prime-order subgroup
+    for k in (1, 2, 3, 0xdeadbeef, C.JUBJUB_SCALAR_MODULUS - 1):
+        naf = C.windowed_naf_2(k)
+        assert sum(d << i for i, d in enumerate(naf)) == k and set(naf) <= {-1, 0, 1}
+        assert all(not (naf[i] and naf[i + 1]) for i in range(255))                # non-adjacent form
+
+
+def test_curve_widgets_prove_and_verify(orc):
+    """Fixed-base scalar multiplication and curve addition gates: accepted by the verifier's ecc terms
+    (widget/ecc/**/verifierkey.rs); a wrong public point cannot be proved."""
+    from zkvm_amd import circuits
+    import plonk_check
+    circ = curve_circuit().tables()
+    assert circ["n"] == 512
+    op, srs, tau = _oracle_prover(orc, circ, b"curve")
+    proof = op.prove(circ["wires"], circ["public_inputs"], circuits.random_blinders(8))
+    assert proof["rc"] == 0
+    sxy, sinf = op.selector_comms()
+    assert not sinf[9] and not sinf[10]
+    h, tau_h = plonk_check.opening_key_g2(tau)
+    assert plonk_check.verify(circ["n"], circ["constraints"], b"curve", proof, sxy, sinf, circ["public_inputs"],
+                              circ["pi_indexes"], srs[0], h, tau_h, orc)
+    bad = curve_circuit(wrong=True).tables()
+    op2, _, _ = _oracle_prover(orc, bad, b"curve")
+    assert op2.prove(bad["wires"], bad["public_inputs"], circuits.random_blinders(8))["rc"] == 2
+
+
+@pytest.mark.gpu
+def test_gpu_proof_with_curve_widgets(orc):
+    import zkvm_amd
+    from zkvm_amd import api, circuits
+    circ = curve_circuit(0xabcdef0123456789).tables()
+    op, srs, _ = _oracle_prover(orc, circ, b"curve")
+    ctx = zkvm_amd.Context(0)
+    try:
+        ctx.srs_load(srs)
+        gp = api.Prover(ctx, circ["n"], circ["constraints"], circ["selectors"].reshape(-1, 4), b"curve", circ["pi_indexes"])
+        bl = circuits.random_blinders(9)
+        want = op.prove(circ["wires"], circ["public_inputs"], bl)
+        got = gp.prove(circ["wires"].reshape(-1, 4), circ["public_inputs"], bl)
+        assert want["rc"] == 0
+        for key in ("challenges", "evals", "comms_inf", "comms"):
+            assert np.array_equal(got[key], want[key]), key
+    finally:
+        ctx.close()

@@ -5,9 +5,10 @@ component_boolean, component_select, constants and public inputs), and the copy-
 `Permutation` (plonk/src/composer/permutation.rs:30-109).  It produces exactly the tables the prover consumes:
 15 selector rows, the sigma map, the four witness columns and the public-input positions.
 
-The range and logic components (composer.rs:224-313, 855-934) are mirrored as well, so that circuits exercising the
-prover's range and logic widgets can be built; the curve components (fixed- and variable-base scalar multiplication)
-are not.  Values are canonical integers modulo r; tables come out as Montgomery limbs.
+The range and logic components (composer.rs:224-313, 855-934), the JubJub point addition (composer.rs:669-703) and
+the fixed-base scalar multiplication (composer.rs:315-443) are mirrored as well, so that circuits exercising every
+widget of the prover can be built; component_mul_point, decomposition and the select-point helpers are compositions
+of these and are left out.  Values are canonical integers modulo r; tables come out as Montgomery limbs.
 """
 import numpy as np
 
@@ -18,6 +19,54 @@ R = circuits.R_MOD
 _COEFFS = ("q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "pi", "q_arith", "q_range", "q_logic", "q_fixed_group_add",
            "q_variable_group_add")
 _EXTERNAL = _COEFFS[:7]          # what Constraint::from_external keeps (constraint.rs:90-104)
+
+
+# ---- JubJub, the twisted Edwards curve -u^2 + v^2 = 1 + d u^2 v^2 over the BLS12-381 scalar field -----------------
+EDWARDS_D = (-10240 * pow(10241, -1, R)) % R                 # coset-jubjub/src/lib.rs:368-373
+assert EDWARDS_D == 0x2a9318e74bfa2b48f5fd9207e6bd7fd4292d7f6d37579d2601065fd6d6343eb1
+JUBJUB_SCALAR_MODULUS = 0x0e7db4ea6533afa906673b0101343b00a6682093ccc81082d0970e5ed6f72cb7   # coset-jubjub/src/fr.rs:76-81
+JUBJUB_GENERATOR = (0x3fd2814c43ac65a6f1fbf02d0fd6cce62e3ebb21fd6c54ed4df7b7ffec7beaca, 0x12)  # coset-jubjub/src/coset.rs:29-42
+JUBJUB_IDENTITY = (0, 1)
+
+
+def jubjub_add(p, q):
+    """affine addition (complete on this curve); the reference adds in extended coordinates and normalises"""
+    (u1, v1), (u2, v2) = p, q
+    t = EDWARDS_D * u1 * u2 % R * v1 % R * v2 % R
+    u3 = (u1 * v2 + v1 * u2) * pow(1 + t, -1, R) % R
+    v3 = (v1 * v2 + u1 * u2) * pow(1 - t, -1, R) % R
+    return (u3, v3)
+
+
+def jubjub_neg(p):
+    return ((-p[0]) % R, p[1])
+
+
+def jubjub_mul(p, k):
+    acc = JUBJUB_IDENTITY
+    while k:
+        if k & 1:
+            acc = jubjub_add(acc, p)
+        p = jubjub_add(p, p)
+        k >>= 1
+    return acc
+
+
+def windowed_naf_2(scalar):
+    """Fr::compute_windowed_naf(2) (coset-jubjub/src/fr/coset.rs:79-109): 256 digits in {-1, 0, 1}, least
+    significant first"""
+    digits = [0] * 256
+    s, i = scalar, 0
+    while s >= 1:
+        if s & 1:
+            d = s & 3
+            if d >= 2:
+                d -= 4
+            digits[i] = d
+            s -= d
+        s >>= 1
+        i += 1
+    return digits
 
 
 class Constraint:
@@ -110,6 +159,18 @@ class Constraint:
         c = Constraint._external(s)
         c.coeff["q_c"] = 1
         c.coeff["q_logic"] = 1
+        return c
+
+    @staticmethod
+    def group_add_fixed_base(s):
+        c = Constraint._external(s)
+        c.coeff["q_fixed_group_add"] = 1
+        return c
+
+    @staticmethod
+    def group_add_variable_base(s):
+        c = Constraint._external(s)
+        c.coeff["q_variable_group_add"] = 1
         return c
 
     @staticmethod
@@ -282,6 +343,69 @@ class Composer:
 
     def append_logic_xor(self, a, b, bit_pairs):
         return self.append_logic_component(a, b, bit_pairs, True)
+
+    def append_point(self, point):
+        """composer.rs:515-525 -> (x witness, y witness)"""
+        return (self.append_witness(point[0]), self.append_witness(point[1]))
+
+    def assert_equal_public_point(self, point, public):
+        """composer.rs:631-649: both coordinates against public inputs"""
+        self.assert_equal_constant(point[0], 0, public[0])
+        self.assert_equal_constant(point[1], 0, public[1])
+
+    def component_add_point(self, a, b):
+        """composer.rs:669-703: one curve-addition gate; the next row carries the result and x1 * y2"""
+        x1, y1 = a
+        x2, y2 = b
+        p3 = jubjub_add((self[x1], self[y1]), (self[x2], self[y2]))
+        x1_y2 = self.append_witness(self[x1] * self[y2])
+        x3 = self.append_witness(p3[0])
+        y3 = self.append_witness(p3[1])
+        self.append_custom_gate(Constraint.group_add_variable_base(Constraint().a(x1).b(y1).c(x2).d(y2)))
+        self.append_custom_gate(Constraint().a(x3).b(y3).d(x1_y2))
+        return (x3, y3)
+
+    def component_mul_generator(self, jubjub, generator=JUBJUB_GENERATOR):
+        """composer.rs:315-443: [jubjub] * generator through 256 fixed-base rounds over the width-2 NAF of the scalar;
+        raises ValueError where the reference returns Error::JubJubScalarMalformed"""
+        bits = 256
+        scalar = self[jubjub]
+        if scalar >= JUBJUB_SCALAR_MODULUS:
+            raise ValueError("JubJubScalarMalformed")
+        multiples = [generator]
+        for _ in range(1, bits):
+            multiples.append(jubjub_add(multiples[-1], multiples[-1]))
+        multiples.reverse()                                   # multiples[i] = 2^(255 - i) * generator
+        naf = windowed_naf_2(scalar)
+        scalar_acc, point_acc, xy_alphas = [0], [JUBJUB_IDENTITY], []
+        for i, entry in enumerate(reversed(naf)):
+            if entry == 0:
+                to_add = JUBJUB_IDENTITY
+            elif entry == 1:
+                to_add = multiples[i]
+            else:
+                to_add = jubjub_neg(multiples[i])
+            scalar_acc.append((2 * scalar_acc[i] + entry) % R)
+            point_acc.append(jubjub_add(point_acc[i], to_add))
+            xy_alphas.append(to_add[0] * to_add[1] % R)
+        for i in range(bits):
+            acc_x = self.append_witness(point_acc[i][0])
+            acc_y = self.append_witness(point_acc[i][1])
+            accumulated_bit = self.append_witness(scalar_acc[i])
+            if i == 0:
+                self.assert_equal_constant(acc_x, 0)
+                self.assert_equal_constant(acc_y, 1)
+                self.assert_equal_constant(accumulated_bit, 0)
+            x_beta, y_beta = multiples[i]
+            xy_alpha = self.append_witness(xy_alphas[i])
+            self.append_custom_gate(Constraint.group_add_fixed_base(Constraint()).left(x_beta).right(y_beta)
+                                    .constant(x_beta * y_beta).a(acc_x).b(acc_y).c(xy_alpha).d(accumulated_bit))
+        acc_x = self.append_witness(point_acc[bits][0])
+        acc_y = self.append_witness(point_acc[bits][1])
+        last_accumulated_bit = self.append_witness(scalar_acc[bits])
+        self.append_gate(Constraint().a(acc_x).b(acc_y).d(last_accumulated_bit))
+        self.assert_equal(last_accumulated_bit, jubjub)
+        return (acc_x, acc_y)
 
     def public_input_indexes(self):
         return sorted(self.public_inputs)

@@ -203,12 +203,46 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPassArgs a) {
     }
 
     // ---- butterflies ----
+    // A zero-padded input (the 8n coset evaluation of an n-coefficient polynomial) leaves most rows of a first-pass
+    // tile zero: `live` counts the leading rows of every butterfly block that can be non-zero.  While live <= hj the
+    // upper operand of every butterfly is zero, so the lower one stays as it is and the upper one becomes x * w;
+    // butterflies whose lower operand is zero as well are skipped.  After such a stage every half block again has
+    // `live` leading rows; the first stage with live > hj fills the blocks and the rest run in full.
+    uint32_t live = R;
+    if (!a.last && pb == 0 && a.len_in < (1ull << a.log_n)) {
+        const uint64_t rows = a.len_in > col0 ? ((a.len_in - col0 - 1) >> a.b0) + 1 : 0;
+        live = rows < R ? (uint32_t)rows : R;
+    }
     uint32_t stage = 0;
     for (uint32_t hj = R >> 1; hj >= 1; hj >>= 1, stage++) {
         __syncthreads();
         const uint32_t h = hj << a.b0;  // half-size of this stage in the whole network
         const uint32_t lhj = 31 - __clz(hj);
         const uint32_t km = stage & 3u;
+        const bool sparse = live <= hj;
+        if (sparse) {
+            for (uint32_t bi = tid; bi < (E >> 1); bi += nt) {
+                const uint32_t t = bi & (T - 1);
+                const uint32_t jb = bi >> a.log_t;
+                const uint32_t off = jb & (hj - 1);
+                if (off >= live) continue;
+                const uint32_t j = ((jb >> lhj) << (lhj + 1)) | off;
+                const uint32_t e0 = j * T + t, e1 = e0 + hj * T;
+                uint32_t x[9], y[9];
+                u9_load(lds, E, e0, x);      // normalised and below 2r: it has only been through products so far
+                if (h > 1 || !a.unit_last) {
+                    const uint32_t widx = (off << a.b0) + col0 + t;
+                    uint32_t w[9];
+                    Fr::unpack(gload(a.tw + (h - 1) + widx), w, 0);
+                    Fr::mul_limbs(x, w, y);
+                    u9_store(lds, E, e1, y);
+                } else {
+                    u9_store(lds, E, e1, x);
+                }
+            }
+            continue;
+        }
+        live = hj;   // blocks are full from here on
         const bool reduce_in = km == 0 && stage > 0;
         uint32_t bias[9];   // literals selected by uniform branches (a table indexed by km would be fetched from memory)
         if (km == 0) ntt_bias<0>(bias);

@@ -11,7 +11,7 @@ workload ntt (BASELINE.json configs[1]): one step = fft(2^20) + ifft(2^20) + cos
   (n+3)-coefficient polynomial on the 8n = 2^23 domain + coset_ifft(2^23), n = 2^20.  Metric: Fr NTT GB/s with
   the algorithmic bytes 2 * N * 32 per N-point transform.  With N GPUs every rank transforms its own batch
   (independent polynomials, no collective): weak scaling.
-workload msm (configs[2]): one step = one 2^22-point G1 MSM; with N GPUs the points are range-sharded, every
+workload msm (configs[2]): one step = one 2^24-point G1 MSM; with N GPUs the points are range-sharded, every
   rank sums its range and the 144-byte partial sums are all-gathered over RCCL and added: strong scaling.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of the workload, timed live with HIP
@@ -207,7 +207,7 @@ def cpu_baseline_ntt():
 
 
 # ---- MSM workload ------------------------------------------------------------------------------------------
-MSM_LOG = 22
+MSM_LOG = 24   # the largest size BASELINE.json names for the commitment MSM; it fits one GPU (35 GiB table)
 
 
 def run_msm(args, rank, world, local, device):
@@ -260,8 +260,9 @@ def run_msm(args, rank, world, local, device):
         out["roofline"] = {"bound": "hbm", "kernel": "msm_accumulate_kernel (this rank's %d points)" % shard,
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 5),
-                           "traffic": pmc_traffic("r01_pmc_msm22.csv", "msm_accumulate_kernel") if shard == 1 << 22 else None,
-                           "traffic_note": "profiles/r01_pmc_msm22.csv: the same kernel on 2^22 points",
+                           "traffic": (pmc_traffic("r01_pmc_msm%d.csv" % (shard.bit_length() - 1), "msm_accumulate_kernel")
+                                       if shard & (shard - 1) == 0 else None),
+                           "traffic_note": "profiles/r01_pmc_msm<log2 points>.csv: the same kernel on the same point count",
                            "avg_launch_ms": round(acc_ms, 4), "algorithmic_bytes_per_launch": int(alg),
                            "valu": {"unit": "G Fq product-equivalents/s", "achieved": round(products, 1), "peak": FQ28_MUL_PEAK_G,
                                     "frac": round(products / FQ28_MUL_PEAK_G, 3)},
@@ -272,14 +273,13 @@ def run_msm(args, rank, world, local, device):
 
 def cpu_baseline_msm():
     from oracle import pyoracle as orc
-    n = 1 << 16
-    pts, _ = orc.g1_multiples_of_generator(1, 1 << 12)
-    pts = np.tile(pts, (n >> 12, 1))
+    n = 1 << 22   # about ten seconds of CPU work on 16 threads
+    pts = tiled_srs(n)
     sc = random_fr(n, 3)
     cores = min(os.cpu_count() or 1, 16)
     _, secs = orc.msm(pts, sc, threads=cores, with_time=True)
     return {"value": round(n / secs / 1e6, 4), "unit": "Mpts/s", "cores": cores, "kind": "port",
-            "sample": "one 2^16-point msm_variable_base (window-parallel as the reference's rayon map); %.1f s" % secs}
+            "sample": "one 2^22-point msm_variable_base (window-parallel as the reference's rayon map); %.1f s" % secs}
 
 
 # ---- prove workload ----------------------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-"""Host-side mirror of the arithmetic part of the reference's circuit front-end: `Constraint`
+"""Host-side mirror of the reference's circuit front-end: `Constraint`
 (plonk/src/composer/constraint_system/constraint.rs) and `Composer` (plonk/src/composer.rs) with the gates the
 Poseidon-Merkle opening circuit uses (poseidon-merkle/src/zk.rs:16-102: gate_add, gate_mul, assert_equal,
 component_boolean, component_select, constants and public inputs), and the copy-constraint bookkeeping of
@@ -183,7 +183,7 @@ class Constraint:
 
 
 class Composer:
-    """composer.rs:36-1015 (arithmetic subset).  Witnesses are indexes into `witnesses`."""
+    """composer.rs:36-1015 (see the module header for what is covered).  Witnesses are indexes into `witnesses`."""
     ZERO, ONE = 0, 1
 
     def __init__(self):               # Composer::uninitialized, composer.rs:154-162

@@ -267,3 +267,18 @@ def test_kzg_opening_checked_by_pairing(ctx, orc):
     assert Pg.pairing_product_is_one([(lhs, h), (neg_w, rhs_g2)])
     wrong = M.ec_add(lhs, g)
     assert not Pg.pairing_product_is_one([(wrong, h), (neg_w, rhs_g2)])
+
+
+def test_msm_fuzz_against_oracle():
+    """Random small point sets with repeated and negated points, points at infinity, colliding scalars and random
+    window / segment widths (tools/fuzz_msm.py): the exceptional cases of the bucket arithmetic, found by chance."""
+    import os
+    import runpy
+    import sys
+    from conftest import ROOT
+    argv = sys.argv
+    sys.argv = ["fuzz_msm.py", "150", "7"]
+    try:
+        runpy.run_path(os.path.join(ROOT, "tools", "fuzz_msm.py"), run_name="__main__")
+    finally:
+        sys.argv = argv

@@ -249,3 +249,18 @@ def test_prove_several_public_inputs(ctx, orc, srs, gates):
             assert np.array_equal(got[key], want[key]), key
     except Exception:
         assert want["rc"] != 0
+
+
+def test_prove_fuzz_random_composer_circuits():
+    """Circuits from random sequences of Composer operations, every widget included, proved on the GPU and by the
+    oracle with the same blinders (tools/fuzz_prove.py)."""
+    import os
+    import runpy
+    import sys
+    from conftest import ROOT
+    argv = sys.argv
+    sys.argv = ["fuzz_prove.py", "40", "11"]
+    try:
+        runpy.run_path(os.path.join(ROOT, "tools", "fuzz_prove.py"), run_name="__main__")
+    finally:
+        sys.argv = argv

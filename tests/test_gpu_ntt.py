@@ -147,3 +147,17 @@ def test_ntt_tile_sizes(ctx, orc, tile_log, ept_log):
                     assert np.array_equal(ctx.ntt(xs, log_n, mode), orc.fft(name, xs, n)), (name, log_n, short)
     finally:
         ctx.ntt_set_params(0, 0)
+
+
+def test_ntt_fuzz_against_oracle():
+    """Random sizes, input lengths, modes and tile geometries (tools/fuzz_ntt.py)."""
+    import os
+    import runpy
+    import sys
+    from conftest import ROOT
+    argv = sys.argv
+    sys.argv = ["fuzz_ntt.py", "150", "5"]
+    try:
+        runpy.run_path(os.path.join(ROOT, "tools", "fuzz_ntt.py"), run_name="__main__")
+    finally:
+        sys.argv = argv

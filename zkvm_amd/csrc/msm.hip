@@ -33,6 +33,7 @@ namespace zk {
 static const uint32_t BIG_BUCKET = 256;   // number of size classes of the schedule (count >> shift, shift grows with the
                                           // mean bucket size); also the floor of the model's oversize allowance
 static const uint32_t BIG_CHUNK = 4096;   // entries per workgroup task
+static const uint32_t TOP_FEW_BITS = 11;  // a top window this short piles its digits on few enough buckets for the task path
 static const uint32_t SCAN_ITEMS = 1024;  // histogram entries scanned per block
 
 struct MsmTask {
@@ -758,7 +759,7 @@ uint32_t MsmEngine::choose_window(size_t n) {
         double oversized = 0, deepest = mean;
         if (top_bits < c - 1) {
             const double extra = (double)n / (double)(1u << top_bits);
-            if (extra > 4 * mean + BIG_BUCKET) oversized = 0.35 + (double)n * 10 / 30e9 * 1e3;
+            if (top_bits <= TOP_FEW_BITS) oversized = 0.35 + (double)n * 10 / 30e9 * 1e3;
             else deepest = mean + extra;
         }
         const double depth = deepest * 0.016, throughput = items * 10 / 61e9 * 1e3;
@@ -905,10 +906,10 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     const uint32_t top_bits = 255 - (K - 1) * c;
     uint64_t expect = max_items >> log_B;
     if (top_bits < log_B) {
-        // a modest share stays with the bucket's thread; a large one (few top-window values) makes those buckets
-        // oversized, as choose_window's model assumes
+        // when thousands of buckets take a share of the top window it is part of their ordinary size; when only a few
+        // do (a top window of at most TOP_FEW_BITS bits) their long chains go to workgroups, as choose_window assumes
         const uint64_t extra = (max_items / K) >> top_bits;
-        if (extra <= 4 * expect + BIG_BUCKET) expect += extra;
+        if (top_bits > TOP_FEW_BITS) expect += extra;
     }
     uint64_t big64 = expect + 16 + (uint64_t)(8.0 * std::sqrt((double)expect));
     uint32_t class_shift = 0;   // size classes are count >> shift, shift the smallest with big <= 256 << shift

@@ -75,3 +75,17 @@ def test_rust_bindings_declare_every_entry_point():
     declared = set(re.findall(r"\b(zkgpu_[a-z0-9_]+)\s*\(", header))
     bound = set(re.findall(r"pub fn (zkgpu_[a-z0-9_]+)", rust))
     assert declared == bound
+
+
+def test_header_is_valid_c_and_cxx(tmp_path):
+    """include/zkgpu.h compiles as C99 and as C++17 on its own (what a cgo / FFI binding generator consumes)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    inc = os.path.join(ROOT, "include")
+    c_src = tmp_path / "use.c"
+    c_src.write_text('#include "zkgpu.h"\nint main(void) { (void)&zkgpu_domain_new; return 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(c_src)])
+    cxx_src = tmp_path / "use.cpp"
+    cxx_src.write_text('#include "zkgpu.h"\nint main() { (void)&zkgpu_domain_new; return 0; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(cxx_src)])

@@ -1,0 +1,18 @@
+"""The C boundary without Python in the process: tests/c_client/client.c is built by __graft_entry__.build() against
+include/zkgpu.h and libzkgpu.so alone and run here as a child process."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_plain_c_client_runs_on_the_gpu():
+    exe = os.path.join(ROOT, "tests", "c_client", "client")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "c client ok" in out.stdout

@@ -749,7 +749,9 @@ size_t MsmEngine::device_bytes() const {
 uint32_t MsmEngine::choose_window(size_t n) {
     uint32_t best = 13;
     double best_ms = 1e300;
-    for (uint32_t c = 4; c <= 22; c++) {
+    // 20 bits at most: beyond 2^19 buckets the sort's range count and the reduction grow faster than the model says
+    // (measured at 2^24 points: 39 ms with 20 bits, 47 ms with 22)
+    for (uint32_t c = 4; c <= 20; c++) {
         const uint32_t K = 255 / c + 1, top_bits = 255 - (K - 1) * c;
         const double B = (double)(1u << (c - 1)), items = (double)n * K, mean = items / B;
         const double log_b = (double)(c - 1);
@@ -759,7 +761,8 @@ uint32_t MsmEngine::choose_window(size_t n) {
         double oversized = 0, deepest = mean;
         if (top_bits < c - 1) {
             const double extra = (double)n / (double)(1u << top_bits);
-            if (top_bits <= TOP_FEW_BITS) oversized = 0.35 + (double)n * 10 / 30e9 * 1e3;
+            // few buckets take the top window's digits: they go to the task path once they pass the oversize threshold
+            if (top_bits <= TOP_FEW_BITS && extra > 8.0 * std::sqrt(mean) + 16.0) oversized = 0.35 + (double)n * 10 / 30e9 * 1e3;
             else deepest = mean + extra;
         }
         const double depth = deepest * 0.016, throughput = items * 10 / 61e9 * 1e3;

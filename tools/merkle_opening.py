@@ -4,6 +4,7 @@ loop; circuit: merkle-plonk/src/lib.rs:117-131).
     python tools/merkle_opening.py HEIGHT [OPENINGS]
 A tree of height H has 4^H leaves; its opening circuit has about 1 010 gates per level."""
 import os
+import random
 import sys
 import time
 
@@ -26,8 +27,8 @@ def main():
     label = b"merkle-opening"
 
     tree = P.Tree(height)
-    rng = np.random.default_rng(height)
-    positions = sorted({int(p) for p in rng.integers(0, tree.capacity(), openings)})
+    rng = random.Random(height)
+    positions = sorted({rng.randrange(tree.capacity()) for _ in range(openings)})
     t0 = time.time()
     for p in positions:
         tree.insert(p, P.digest(P.Domain.OTHER, [p])[0])

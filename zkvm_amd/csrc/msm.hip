@@ -464,19 +464,50 @@ __global__ void msm_schedule_scan_kernel(uint32_t *class_cursor) {
 }
 
 // ---- bucket accumulation ----------------------------------------------------------------------------------
+// 2^LOG_P neighbouring lanes share a bucket: lane `part` adds entries part, part + P, ... and the partial sums
+// meet through lane shuffles.  With fewer buckets than the chip has lanes the launch is bound by the longest chain
+// of dependent additions on one lane, which the split shortens; LOG_P = 0 is the plain one-lane-per-bucket form.
+__device__ __forceinline__ G1Xyzz shfl_down_xyzz(const G1Xyzz &p, uint32_t delta) {
+    G1Xyzz r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        r.x.v[i] = __shfl_down(p.x.v[i], delta);
+        r.y.v[i] = __shfl_down(p.y.v[i], delta);
+        r.zz.v[i] = __shfl_down(p.zz.v[i], delta);
+        r.zzz.v[i] = __shfl_down(p.zzz.v[i], delta);
+    }
+    return r;
+}
+// Sum j = first_sum + blockIdx.y of a batch owns buckets [j B, (j + 1) B) and the class cursors
+// [j (N_CLASSES + 1), ...), whose last entry is its number of scheduled buckets.
+template <int LOG_P>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const G1Table28 *points, const uint32_t *sorted,
                                                              const uint32_t *offsets, const uint32_t *counts,
-                                                             const uint32_t *order, const uint32_t *n_scheduled,
-                                                             G1Xyzz *buckets) {
-    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= *n_scheduled) return;
-    const uint32_t b = order[gid];
+                                                             const uint32_t *order, const uint32_t *class_cursor,
+                                                             G1Xyzz *buckets, uint32_t B, uint32_t first_sum) {
+    constexpr uint32_t P = 1u << LOG_P;
+    const uint32_t j = first_sum + blockIdx.y;
+    offsets += (size_t)j * B;
+    counts += (size_t)j * B;
+    order += (size_t)j * B;
+    buckets += (size_t)j * B;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = gid >> LOG_P, part = gid & (P - 1);
+    if (slot >= class_cursor[(size_t)j * (N_CLASSES + 1) + N_CLASSES]) return;   // the same for all P lanes of a bucket
+    const uint32_t b = order[slot];
     const uint32_t cnt = counts[b], start = offsets[b];
     G1Xyzz acc = G1Xyzz::identity();
-    for (uint32_t k = 0; k < cnt; k++) {
+    for (uint32_t k = part; k < cnt; k += P) {
         uint32_t v = sorted[start + k];
         G1Affine28 p = gload_affine28(points + (v & 0x7fffffffu));
         acc = xyzz_add_mixed(acc, p, (v >> 31) != 0);
+    }
+    if (LOG_P) {
+        for (uint32_t s = P >> 1; s >= 1; s >>= 1) {
+            const G1Xyzz other = shfl_down_xyzz(acc, s);
+            if (part < s) acc = xyzz_add(acc, other);
+        }
+        if (part) return;
     }
     gstore_xyzz(buckets + b, acc);
 }
@@ -739,11 +770,12 @@ size_t MsmEngine::device_bytes() const {
 
 // Window width for a table of n points, from a time model (milliseconds) fitted to MI355X measurements
 // (tools/msm_window_sweep.py).  K = floor(255 / c) + 1 signed digits always cover a 255-bit scalar.
-//   accumulate: one thread per bucket, so it is the larger of the throughput term (10 products per addition at the
-//               achieved ~61 G products/s) and the depth term: the deepest bucket's additions at ~16 us each — few
-//               buckets mean long dependent chains on a mostly idle chip;
-//   reduce:     ~0.3 ms of latency plus the work of 2 additions per bucket;
-//   sort:       ~27 ps per (scalar, digit) pair;
+//   accumulate: the larger of the throughput term (10 products per addition at the achieved ~61 G products/s) and
+//               the depth term: the deepest bucket's additions at ~16 us each on one lane (up to four lanes share a
+//               bucket when there are at most 2^15 of them) — few buckets mean long dependent chains on a mostly
+//               idle chip;
+//   reduce:     0.2-0.3 ms of latency plus the work of 2 additions per bucket;
+//   sort:       ~80 ps per (scalar, digit) pair in one level, ~21 ps through the range partition;
 //   a short top window (255 - (K-1) c bits) piles its n digits onto 2^top buckets, all levels sharing one bucket
 //   set: they either deepen the deepest bucket or go through the oversized-bucket path.
 uint32_t MsmEngine::choose_window(size_t n) {
@@ -755,9 +787,11 @@ uint32_t MsmEngine::choose_window(size_t n) {
         const uint32_t K = 255 / c + 1, top_bits = 255 - (K - 1) * c;
         const double B = (double)(1u << (c - 1)), items = (double)n * K, mean = items / B;
         const double log_b = (double)(c - 1);
-        double reduce = 0.29 + 0.0125 * ((log_b < 16 ? log_b : 16) > 7 ? (log_b < 16 ? log_b : 16) - 7 : 0);
+        double reduce = 0.20 + 0.0125 * ((log_b < 16 ? log_b : 16) > 7 ? (log_b < 16 ? log_b : 16) - 7 : 0);
+        if (B > 32768.0) reduce += 0.09;   // 8- or 16-bucket segments there, 4-bucket ones below
         if (B > 65536.0) reduce += (B - 65536.0) * 0.5e-6;
-        const double sort = 0.06 + items * 27e-9;
+        // one-level sort (LDS counters for all buckets) up to 2^15 buckets, range partition + sort above
+        const double sort = log_b <= 15 ? 0.03 + items * 80e-9 : 0.08 + items * 21e-9;
         double oversized = 0, deepest = mean;
         if (top_bits < c - 1) {
             const double extra = (double)n / (double)(1u << top_bits);
@@ -765,7 +799,16 @@ uint32_t MsmEngine::choose_window(size_t n) {
             if (top_bits <= TOP_FEW_BITS && extra > 8.0 * std::sqrt(mean) + 16.0) oversized = 0.35 + (double)n * 10 / 30e9 * 1e3;
             else deepest = mean + extra;
         }
-        const double depth = deepest * 0.016, throughput = items * 10 / 61e9 * 1e3;
+        // up to 2^15 buckets, up to four lanes share a bucket (two combining additions at the end)
+        double depth = deepest * 0.016;
+        if (log_b <= 15) {
+            uint32_t log_p = 0;
+            while (log_p < 2 && deepest / (double)(1u << log_p) >= 6.0) log_p++;
+            depth = deepest / (double)(1u << log_p) * 0.016 + log_p * 0.02;
+        }
+        // the first entry of a bucket is a copy, not an addition
+        const double additions = items - B * (1.0 - std::exp(-mean));
+        const double throughput = additions * 10 / 61e9 * 1e3;
         const double ms = (depth > throughput ? depth : throughput) + 0.05 + reduce + sort + oversized;
         if (ms < best_ms) {
             best_ms = ms;
@@ -922,7 +965,8 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     // every oversized bucket gives ceil(count / BIG_CHUNK) tasks: at most one per `big` entries plus one per chunk
     const uint32_t max_tasks = (uint32_t)(total_items / big + total_items / BIG_CHUNK + m);
     const uint32_t n_scan_blocks = ceil_div(nb, SCAN_ITEMS);
-    const uint32_t seg_bits = seg_bits_ ? seg_bits_ : (m >= 3 ? 4u : 3u);
+    // segments of the bucket reduction: few buckets leave the chip idle, so short segments (shallow chains) win there
+    const uint32_t seg_bits = seg_bits_ ? seg_bits_ : (log_B <= 15 ? 2u : (m >= 3 ? 4u : 3u));
     const uint32_t log_seg = log_B < seg_bits ? log_B : seg_bits;
     const uint32_t segs_per_sum = 1u << (log_B - log_seg);
     const uint32_t n_bits = log_B - log_seg;
@@ -1062,11 +1106,25 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
         hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024)), dim3(1024), 0, stream_, cnt, B, class_shift, big, cc, ord);
     }
     if (profile_) ZK_HIP(hipEventRecord(profile_[1], stream_));
-    for (uint32_t j = 0; j < m; j++) {
-        uint32_t *cc = class_cursor + (size_t)j * (N_CLASSES + 1);
-        hipLaunchKernelGGL(msm_accumulate_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, table, sorted_.as<uint32_t>(),
-                           offsets_.as<uint32_t>() + (size_t)j * B, counts_.as<uint32_t>() + (size_t)j * B,
-                           order + (size_t)j * B, cc + N_CLASSES, buckets_.as<G1Xyzz>() + (size_t)j * B);
+    // Up to 2^15 buckets per sum the launch is bound by the longest chain of additions on one lane, not by throughput:
+    // the sums of a batch then share one launch, and two or four lanes share each bucket while the chains are worth
+    // cutting (measured on 2^15-gate proofs: 8.8 ms with one lane per bucket and one launch per sum, 6.1 ms this way).
+    // Larger bucket sets run one launch per sum (a single launch over all m * B buckets runs measurably slower there)
+    // with one lane per bucket.
+    const bool fused = log_B <= 15 && m > 1;
+    uint32_t log_p = 0;
+    while (log_B <= 15 && log_p < 2 && (expect >> log_p) >= 6) log_p++;
+    {
+        const dim3 grid(ceil_div((uint64_t)B << log_p, 256), fused ? m : 1);
+        for (uint32_t j = 0; j < (fused ? 1u : m); j++) {
+            auto launch = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream_, table, sorted_.as<uint32_t>(), offsets_.as<uint32_t>(),
+                                   counts_.as<uint32_t>(), order, class_cursor, buckets_.as<G1Xyzz>(), B, j);
+            };
+            if (log_p == 0) launch(msm_accumulate_kernel<0>);
+            else if (log_p == 1) launch(msm_accumulate_kernel<1>);
+            else launch(msm_accumulate_kernel<2>);
+        }
     }
     if (profile_) ZK_HIP(hipEventRecord(profile_[2], stream_));
     const uint32_t big_grid = max_tasks < 2048 ? max_tasks : 2048;

@@ -239,8 +239,11 @@ struct Fp_ {
         return res;
     }
     FF_HD static Fp_ pow_u64(const Fp_ &a, uint64_t e) {
-        Fp_ res = one();
-        for (int b = 63; b >= 0; b--) {
+        if (e == 0) return one();
+        int top = 63;   // squarings start below the highest set bit: small exponents (thread indexes) cost few products
+        while (!((e >> top) & 1)) top--;
+        Fp_ res = a;
+        for (int b = top - 1; b >= 0; b--) {
             res = sqr(res);
             if ((e >> b) & 1) res = mul(res, a);
         }

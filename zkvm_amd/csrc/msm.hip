@@ -148,8 +148,24 @@ __device__ __forceinline__ void gstore_proj(G1Proj *p, const G1Proj &r) {
     gstore_fq(q + 6, r.z);
 }
 
+// Geometry of one sum's counting sort: slice = ceil(n_items / S)
+struct SortGeom {
+    uint32_t n_items, n, stride, base, B, log_range, S, slice;
+};
+// Per-sum arguments of a batch, passed by value: the small kernels below serve sum first_sum + blockIdx.y (or .z),
+// so one launch covers either a single sum or the whole batch.
+struct SumArgs {
+    const Fr *scalars[MsmEngine::MAX_BATCH];
+    uint32_t *dig[MsmEngine::MAX_BATCH];
+    SortGeom g[MsmEngine::MAX_BATCH];
+};
+
 // dig[w * n + i] = |digit| | sign << 31 of scalar i in window w (0 when the digit is zero)
-__global__ void __launch_bounds__(256) msm_digits_kernel(const Fr *scalars, uint32_t n, uint32_t c, uint32_t K, uint32_t *dig) {
+__global__ void __launch_bounds__(256) msm_digits_kernel(SumArgs a, uint32_t first_sum, uint32_t c, uint32_t K) {
+    const uint32_t sum = first_sum + blockIdx.y;
+    const Fr *scalars = a.scalars[sum];
+    uint32_t *dig = a.dig[sum];
+    const uint32_t n = a.g[sum].n;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr s = Fr::from_mont(gload_fr(scalars + i));
@@ -176,14 +192,18 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const Fr *scalars, uint
 //   pass 0 (count):   part[s * B + bucket] = number of slice entries in the bucket
 //   pass 1 (scatter): part[...] holds the first output position for (s, bucket); the table index
 //                     w * stride + base + i of every entry is written there
-struct SortGeom {
-    uint32_t n_items, n, stride, base, B, log_range, S, slice;  // slice = ceil(n_items / S)
-};
+// Sum first_sum + blockIdx.z; its counters start at part + sum * part_stride.
 template <int PASS>
-__global__ void __launch_bounds__(1024) msm_sort_kernel(const uint32_t *dig, SortGeom g, uint32_t *part, uint32_t *sorted) {
+__global__ void __launch_bounds__(1024) msm_sort_kernel(SumArgs a, uint32_t first_sum, uint32_t *part, size_t part_stride,
+                                                        uint32_t *sorted) {
     extern __shared__ uint32_t hist[];
+    const uint32_t sum = first_sum + blockIdx.z;
+    const SortGeom g = a.g[sum];
+    const uint32_t *dig = a.dig[sum];
+    part += (size_t)sum * part_stride;
     const uint32_t range = 1u << g.log_range;
     const uint32_t s = blockIdx.x, r = blockIdx.y;
+    if (s >= g.S) return;   // the grid is sized for the sum with the most slices
     uint32_t *mine = part + (size_t)s * g.B + ((size_t)r << g.log_range);
     for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) hist[t] = PASS ? mine[t] : 0u;
     __syncthreads();
@@ -323,7 +343,12 @@ __global__ void __launch_bounds__(1024) msm_sort2_kernel(const uint32_t *mid_key
 }
 
 // counts[b] = sum over slices
-__global__ void __launch_bounds__(256) msm_totals_kernel(const uint32_t *part, uint32_t B, uint32_t S, uint32_t *counts) {
+__global__ void __launch_bounds__(256) msm_totals_kernel(SumArgs a, uint32_t first_sum, const uint32_t *part, size_t part_stride,
+                                                         uint32_t *counts) {
+    const uint32_t sum = first_sum + blockIdx.y;
+    const uint32_t B = a.g[sum].B, S = a.g[sum].S;
+    part += (size_t)sum * part_stride;
+    counts += (size_t)sum * B;
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     uint32_t tot = 0;
@@ -331,7 +356,12 @@ __global__ void __launch_bounds__(256) msm_totals_kernel(const uint32_t *part, u
     counts[b] = tot;
 }
 // part[...] <- first output position of every (slice, bucket)
-__global__ void __launch_bounds__(256) msm_cursors_kernel(uint32_t *part, const uint32_t *offsets, uint32_t B, uint32_t S) {
+__global__ void __launch_bounds__(256) msm_cursors_kernel(SumArgs a, uint32_t first_sum, uint32_t *part, size_t part_stride,
+                                                          const uint32_t *offsets) {
+    const uint32_t sum = first_sum + blockIdx.y;
+    const uint32_t B = a.g[sum].B, S = a.g[sum].S;
+    part += (size_t)sum * part_stride;
+    offsets += (size_t)sum * B;
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     uint32_t run = offsets[b];
@@ -430,9 +460,14 @@ static const uint32_t N_CLASSES = BIG_BUCKET + 1;
 
 template <int PASS>
 __global__ void __launch_bounds__(1024) msm_schedule_kernel(const uint32_t *counts, uint32_t nb, uint32_t shift,
-                                                            uint32_t big, uint32_t *class_cursor, uint32_t *order) {
+                                                            uint32_t big, uint32_t *class_cursor, uint32_t *order,
+                                                            uint32_t first_sum) {
     __shared__ uint32_t hist[N_CLASSES];
     __shared__ uint32_t base[N_CLASSES];
+    const uint32_t sum = first_sum + blockIdx.y;   // its nb buckets, class cursors and order follow the previous sum's
+    counts += (size_t)sum * nb;
+    order += (size_t)sum * nb;
+    class_cursor += (size_t)sum * (N_CLASSES + 1);
     for (uint32_t t = threadIdx.x; t < N_CLASSES; t += blockDim.x) hist[t] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -452,8 +487,9 @@ __global__ void __launch_bounds__(1024) msm_schedule_kernel(const uint32_t *coun
     if (cls != 0xffffffffu) order[base[cls] + rank] = i;
 }
 // exclusive scan of the class histogram (in place), total scheduled buckets in class_cursor[N_CLASSES]
-__global__ void msm_schedule_scan_kernel(uint32_t *class_cursor) {
-    if (threadIdx.x || blockIdx.x) return;
+__global__ void msm_schedule_scan_kernel(uint32_t *class_cursor, uint32_t first_sum) {
+    if (threadIdx.x) return;
+    class_cursor += (size_t)(first_sum + blockIdx.x) * (N_CLASSES + 1);
     uint32_t run = 0;
     for (uint32_t t = 0; t < N_CLASSES; t++) {
         uint32_t v = class_cursor[t];
@@ -1028,31 +1064,50 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     ZK_HIP(hipMemsetAsync(class_cursor, 0, (size_t)m * (N_CLASSES + 1) * 4, stream_));
 
     if (profile_) ZK_HIP(hipEventRecord(profile_[0], stream_));
-    // per sum: digits and the count pass of its own items into its own B counters
-    SortGeom geom[MAX_BATCH];
-    uint32_t *dig[MAX_BATCH];
+    // per sum: digits and the count pass of its own items into its own B counters.  With one bucket range the
+    // launches are small and bound by latency, so each covers the whole batch.
+    SumArgs sums;
+    SortGeom *geom = sums.g;
+    uint32_t **dig = sums.dig;
     uint64_t item_base = 0;
-    for (uint32_t j = 0; j < m; j++) {
-        const uint64_t n_items = (uint64_t)lens[j] * K;
+    size_t max_len = 0;
+    uint32_t S_used = 1;
+    for (uint32_t j = 0; j < MAX_BATCH; j++) {
+        const uint32_t k = j < m ? j : 0;   // unused entries repeat sum 0
+        const uint64_t n_items = (uint64_t)lens[k] * K;
         uint32_t S = S_max;
         while (S > 1 && n_items / S < 8192) S >>= 1;  // keep slices long enough to amortise the histogram flush
         geom[j].n_items = (uint32_t)n_items;
-        geom[j].n = (uint32_t)lens[j];
+        geom[j].n = (uint32_t)lens[k];
         geom[j].stride = (uint32_t)n_points_;
         geom[j].base = (uint32_t)base;
         geom[j].B = B;
         geom[j].log_range = log_range;
         geom[j].S = S;
         geom[j].slice = (uint32_t)((n_items + S - 1) / S);
-        dig[j] = digits_.as<uint32_t>() + item_base;
-        item_base += n_items;
-        uint32_t *part = cursor_.as<uint32_t>() + (size_t)j * B * S_max;
-        hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(lens[j], 256)), dim3(256), 0, stream_, scalars_dev[j],
-                           (uint32_t)lens[j], c, K, dig[j]);
-        if (n_ranges == 1) {
-            hipLaunchKernelGGL(msm_sort_kernel<0>, dim3(S, n_ranges), dim3(1024), lds_bytes, stream_, dig[j], geom[j], part,
-                               sorted_.as<uint32_t>());
+        sums.scalars[j] = scalars_dev[k];
+        if (j < m) {
+            dig[j] = digits_.as<uint32_t>() + item_base;
+            item_base += n_items;
+            if (lens[j] > max_len) max_len = lens[j];
+            if (S > S_used) S_used = S;
         } else {
+            dig[j] = dig[0];
+        }
+    }
+    const size_t part_stride = (size_t)B * S_max;
+    uint32_t *const part_all = cursor_.as<uint32_t>();
+    const bool batched = n_ranges == 1 && m > 1;
+    const uint32_t n_launch = batched ? 1u : m, per_launch = batched ? m : 1u;
+    for (uint32_t j = 0; j < n_launch; j++) {
+        const size_t len_j = batched ? max_len : lens[j];
+        hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(len_j, 256), per_launch), dim3(256), 0, stream_, sums, j, c, K);
+        if (n_ranges == 1) {
+            hipLaunchKernelGGL(msm_sort_kernel<0>, dim3(batched ? S_used : geom[j].S, 1, per_launch), dim3(1024), lds_bytes, stream_,
+                               sums, j, part_all, part_stride, sorted_.as<uint32_t>());
+        } else {
+            uint32_t *part = part_all + (size_t)j * part_stride;
+            const uint64_t n_items = geom[j].n_items;
             // range partition: count, scan (range-major, one extra entry = the total), place
             const uint32_t n_blocks = ceil_div(n_items, RANGE_ITEMS), n_cnt = n_ranges * n_blocks + 1;
             const uint32_t n_cnt_blocks = ceil_div(n_cnt, SCAN_ITEMS);
@@ -1068,11 +1123,11 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             hipLaunchKernelGGL(msm_range_kernel<1>, dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
                                blockcnt, mkey, mval);
             // msm_range_kernel<1> advanced nothing in global memory: blockcnt still holds the start positions
-            hipLaunchKernelGGL(msm_sort2_kernel<0>, dim3(S * n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt, n_blocks,
+            hipLaunchKernelGGL(msm_sort2_kernel<0>, dim3(geom[j].S * n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt, n_blocks,
                                geom[j], part, sorted_.as<uint32_t>());
         }
-        hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, part, B, S,
-                           counts_.as<uint32_t>() + (size_t)j * B);
+        hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(B, 256), per_launch), dim3(256), 0, stream_, sums, j, part_all,
+                           part_stride, counts_.as<uint32_t>());
     }
     // one scan over all m * B buckets: every bucket's run in `sorted`
     hipLaunchKernelGGL(scan_block_kernel, dim3(n_scan_blocks), dim3(256), 0, stream_, counts_.as<uint32_t>(),
@@ -1080,14 +1135,14 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream_, block_sums_.as<uint32_t>(), n_scan_blocks);
     hipLaunchKernelGGL(scan_finish_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, counts_.as<uint32_t>(),
                        offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb, big, tasks_.as<MsmTask>(), task_count, max_tasks);
-    for (uint32_t j = 0; j < m; j++) {
-        uint32_t *part = cursor_.as<uint32_t>() + (size_t)j * B * S_max;
-        hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, part,
-                           offsets_.as<uint32_t>() + (size_t)j * B, B, geom[j].S);
+    for (uint32_t j = 0; j < n_launch; j++) {
+        hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(B, 256), per_launch), dim3(256), 0, stream_, sums, j, part_all,
+                           part_stride, offsets_.as<uint32_t>());
         if (n_ranges == 1) {
-            hipLaunchKernelGGL(msm_sort_kernel<1>, dim3(geom[j].S, n_ranges), dim3(1024), lds_bytes, stream_, dig[j], geom[j], part,
-                               sorted_.as<uint32_t>());
+            hipLaunchKernelGGL(msm_sort_kernel<1>, dim3(batched ? S_used : geom[j].S, 1, per_launch), dim3(1024), lds_bytes, stream_,
+                               sums, j, part_all, part_stride, sorted_.as<uint32_t>());
         } else {
+            uint32_t *part = part_all + (size_t)j * part_stride;
             const uint32_t n_blocks = ceil_div(geom[j].n_items, RANGE_ITEMS);
             const uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
             const uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
@@ -1095,15 +1150,13 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
                                n_blocks, geom[j], part, sorted_.as<uint32_t>());
         }
     }
-    // schedule (class histogram, scan, placement) and accumulation, one sum after the other: the launches of a
-    // batch are kept apart because one launch over all m * B buckets runs measurably slower than m over B
-    for (uint32_t j = 0; j < m; j++) {
-        uint32_t *cc = class_cursor + (size_t)j * (N_CLASSES + 1);
-        uint32_t *ord = order + (size_t)j * B;
-        const uint32_t *cnt = counts_.as<uint32_t>() + (size_t)j * B;
-        hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024)), dim3(1024), 0, stream_, cnt, B, class_shift, big, cc, ord);
-        hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(1), dim3(64), 0, stream_, cc);
-        hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024)), dim3(1024), 0, stream_, cnt, B, class_shift, big, cc, ord);
+    // schedule (class histogram, scan, placement) per sum
+    for (uint32_t j = 0; j < n_launch; j++) {
+        hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024), per_launch), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
+                           class_shift, big, class_cursor, order, j);
+        hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(per_launch), dim3(64), 0, stream_, class_cursor, j);
+        hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024), per_launch), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
+                           class_shift, big, class_cursor, order, j);
     }
     if (profile_) ZK_HIP(hipEventRecord(profile_[1], stream_));
     // Up to 2^15 buckets per sum the launch is bound by the longest chain of additions on one lane, not by throughput:

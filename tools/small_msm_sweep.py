@@ -25,19 +25,18 @@ def main():
         ctx.msm_set_params(window, 0)
         ctx.srs_setup(circuits.seeded_tau(), circuits.g1_generator_limbs(), n)
         rows = []
-        for split in (0,):
-            for seg in segments:
-                ctx.msm_set_params(window, seg)
-                got = ctx.msm(sc)
-                want = want if want is not None else got
-                assert np.array_equal(got[0], want[0]), "result changed"
-                best = None
-                for _ in range(5):
-                    ms = ctx.msm_profile(sc)
-                    if best is None or sum(ms.values()) < sum(best.values()):
-                        best = ms
-                rows.append((sum(best.values()), split, seg, best))
-        for total, split, seg, best in sorted(rows, key=lambda r: r[0])[:4]:
+        for seg in segments:
+            ctx.msm_set_params(window, seg)
+            got = ctx.msm(sc)
+            want = want if want is not None else got
+            assert np.array_equal(got[0], want[0]), "result changed"
+            best = None
+            for _ in range(5):
+                ms = ctx.msm_profile(sc)
+                if best is None or sum(ms.values()) < sum(best.values()):
+                    best = ms
+            rows.append((sum(best.values()), seg, best))
+        for total, seg, best in sorted(rows, key=lambda r: r[0])[:4]:
             print("2^%d window %s seg %d: " % (log_n, ctx.msm_get_params(), seg)
                   + "  ".join("%s %.3f" % kv for kv in best.items()) + "  total %.3f" % total, flush=True)
         ctx.close()

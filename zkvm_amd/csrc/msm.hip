@@ -1076,7 +1076,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
         const uint32_t k = j < m ? j : 0;   // unused entries repeat sum 0
         const uint64_t n_items = (uint64_t)lens[k] * K;
         uint32_t S = S_max;
-        while (S > 1 && n_items / S < 8192) S >>= 1;  // keep slices long enough to amortise the histogram flush
+        while (S > 1 && n_items / S < 16384) S >>= 1;  // keep slices long enough to amortise the histogram flush
         geom[j].n_items = (uint32_t)n_items;
         geom[j].n = (uint32_t)lens[k];
         geom[j].stride = (uint32_t)n_points_;

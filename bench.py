@@ -50,7 +50,7 @@ def pmc_traffic(profile_csv, kernel):
     if not os.path.exists(path):
         return None
     for row in csv.DictReader(open(path)):
-        if row["kernel"].endswith(kernel):
+        if row["kernel"].split("<")[0].endswith(kernel):      # template arguments dropped
             return int(row["hbm_read_bytes_corrected"]) + int(row["hbm_write_bytes"])
     return None
 

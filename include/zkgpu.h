@@ -146,6 +146,14 @@ int zkgpu_msm_profile_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, flo
  * coefficients as held by the reference's Polynomial (leading zeros allowed; the degree is computed as
  * Polynomial::degree does).  ZKGPU_ERR_DEGREE_ZERO / ZKGPU_ERR_DEGREE_LARGE mirror the reference's errors. */
 int zkgpu_commit(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, uint64_t out_xy[12], uint8_t *out_infinity);
+/* The commitments of one proof round in one pass, as the reference's prover makes them one after the other
+ * (compiler/prover.rs:262-265 the four wires, :344-347 the four quotient parts, :463-485 the two openings): up to 4
+ * polynomials over the same SRS share the sort and reduction launches of a batched MSM.  coeffs[j] is a host buffer
+ * of lens[j] coefficients; out_xy receives 12 limbs and out_infinity one flag per polynomial.  The degree checks of
+ * zkgpu_commit run in order before any work and the first failure is returned, as the reference returns its first
+ * error. */
+int zkgpu_commit_many(zkgpu_ctx *ctx, uint32_t count, const uint64_t *const *coeffs, const size_t *lens, uint64_t *out_xy,
+                      uint8_t *out_infinity);
 
 /* Host-only self-check of the Montgomery product the kernels are built on (the same source compiles for host and
  * device): field 0 = Fr (4 limbs per element), 1 = Fq (6 limbs); out[i] = a[i] * b[i] for count elements. */

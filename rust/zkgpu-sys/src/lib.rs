@@ -76,6 +76,8 @@ extern "C" {
     pub fn zkgpu_msm_profile_dev(ctx: *mut zkgpu_ctx, scalars_dev: *const c_void, n: usize, phase_ms: *mut f32) -> c_int;
     pub fn zkgpu_commit(ctx: *mut zkgpu_ctx, coeffs: *const u64, len: usize, out_xy: *mut u64, out_infinity: *mut u8)
                         -> c_int;
+    pub fn zkgpu_commit_many(ctx: *mut zkgpu_ctx, count: u32, coeffs: *const *const u64, lens: *const usize, out_xy: *mut u64,
+                             out_infinity: *mut u8) -> c_int;
     pub fn zkgpu_field_mul_selfcheck(field: c_int, a: *const u64, b: *const u64, count: usize, out: *mut u64) -> c_int;
     pub fn zkgpu_g1_bucket_selfcheck(xy: *const u64, infinity: *const u8, negate: *const u8, n: usize, out_xyz: *mut u64,
                                      violations: *mut u64) -> c_int;

@@ -113,6 +113,34 @@ def test_commit_degree_checks(ctx, orc):
     assert np.array_equal(xy2, xy)
 
 
+@pytest.mark.parametrize("n", [300, 5000, 1 << 15])
+def test_commit_many_ragged_batches(ctx, orc, n):
+    """zkgpu_commit_many: up to four polynomials of very different lengths in one batched pass (shared sort,
+    accumulate and reduction launches) give the commitments of four separate zkgpu_commit calls = the oracle's."""
+    import zkvm_amd
+    pts, _ = orc.g1_multiples_of_generator(5, n)
+    ctx.srs_load(pts)
+    lens = [n, 2, n // 3 + 1, n - 1]
+    polys = [M.random_fr_mont(k, 900 + k) for k in lens]
+    polys[3][n // 2:] = 0                                   # leading zeros: the degree is what counts
+    polys[2][::2] = M.fr_to_mont(M.R_MOD - 1)               # half the scalars equal: deep buckets
+    for m in (4, 3, 2, 1):
+        got = ctx.commit_many(polys[:m])
+        assert len(got) == m
+        for j in range(m):
+            want_xy, want_inf = oracle_affine(orc, pts[:lens[j]], polys[j])
+            assert got[j][1] == want_inf and np.array_equal(got[j][0], want_xy), (m, j)
+    one_xy, _ = ctx.commit(polys[2])
+    assert np.array_equal(ctx.commit_many([polys[2]])[0][0], one_xy)
+    # the first failing degree check is the error returned, before any work (prover.rs:262-265)
+    with pytest.raises(zkvm_amd.PolynomialDegreeIsZero):
+        ctx.commit_many([polys[0], M.fr_vec_to_mont([7, 0, 0]), M.random_fr_mont(n + 5, 1)])
+    with pytest.raises(zkvm_amd.PolynomialDegreeTooLarge):
+        ctx.commit_many([polys[0], M.random_fr_mont(n + 5, 1), M.fr_vec_to_mont([7])])
+    with pytest.raises(zkvm_amd.ZkGpuError):
+        ctx.commit_many([polys[0]] * 5)
+
+
 def test_msm_2_16_device_scalars_and_sharding(ctx, orc):
     """65536 distinct points (tau-powers SRS), scalars resident in HBM; the two half-range partial sums add up to
     the full result (the point-range sharding used across GPUs)."""

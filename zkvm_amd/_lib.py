@@ -59,6 +59,7 @@ SIGNATURES = {
     "zkgpu_g1_sum_to_affine": (C.c_int, [_P, C.c_size_t, _P, _P]),
     "zkgpu_msm_kernels_dev": (C.c_int, [_P, _P, C.c_size_t]),
     "zkgpu_commit": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
+    "zkgpu_commit_many": (C.c_int, [_P, C.c_uint32, _P, _P, _P, _P]),
     "zkgpu_g1_compress": (C.c_int, [_P, C.c_uint8, _P]),
     "zkgpu_ntt_set_params": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "zkgpu_srs_setup": (C.c_int, [_P, _P, _P, C.c_size_t]),

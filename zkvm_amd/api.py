@@ -192,6 +192,21 @@ class Context:
         return out, int(inf.value)
 
 
+def _commit_many(self, polys):
+    """Up to four KZG commitments in one batched MSM -> [(xy limbs, infinity flag), ...] (zkgpu_commit_many)."""
+    arrs = [_np_u64(p, 4) for p in polys]
+    m = len(arrs)
+    ptrs = (C.c_void_p * m)(*[a.ctypes.data for a in arrs])
+    lens = (C.c_size_t * m)(*[a.shape[0] for a in arrs])
+    out = np.zeros((m, 12), dtype=np.uint64)
+    inf = np.zeros(m, dtype=np.uint8)
+    self._check(self._lib.zkgpu_commit_many(self._h, m, ptrs, lens, out.ctypes.data, inf.ctypes.data))
+    return [(out[j], int(inf[j])) for j in range(m)]
+
+
+Context.commit_many = _commit_many
+
+
 def g1_sum_to_affine(xyz):
     pts = _np_u64(xyz, 18)
     out = np.zeros(12, dtype=np.uint64)

@@ -350,6 +350,44 @@ int zkgpu_commit(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, uint64_t ou
     });
 }
 
+int zkgpu_commit_many(zkgpu_ctx *ctx, uint32_t count, const uint64_t *const *coeffs, const size_t *lens, uint64_t *out_xy,
+                      uint8_t *out_infinity) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(count >= 1 && count <= MsmEngine::MAX_BATCH, ZKGPU_ERR_INVALID_ARG, "commit_many: 1 to 4 polynomials");
+        ZK_REQUIRE(coeffs != nullptr && lens != nullptr && out_xy != nullptr, ZKGPU_ERR_INVALID_ARG, "commit_many: null argument");
+        ZK_REQUIRE(ctx->msm->n_points() > 0, ZKGPU_ERR_NOT_LOADED, "commit_many: no SRS loaded");
+        const size_t n_points = ctx->msm->n_points();
+        size_t take[MsmEngine::MAX_BATCH], total = 0;
+        for (uint32_t j = 0; j < count; j++) {
+            ZK_REQUIRE(coeffs[j] != nullptr || lens[j] == 0, ZKGPU_ERR_INVALID_ARG, "commit_many: null polynomial");
+            size_t degree = 0;   // Polynomial::degree (plonk/src/fft/polynomial.rs:79-93)
+            for (size_t i = lens[j]; i-- > 0;) {
+                const uint64_t *c = coeffs[j] + 4 * i;
+                if (c[0] | c[1] | c[2] | c[3]) {
+                    degree = i;
+                    break;
+                }
+            }
+            ZK_REQUIRE(degree != 0, ZKGPU_ERR_DEGREE_ZERO, "PolynomialDegreeIsZero");
+            ZK_REQUIRE(degree <= n_points - 1, ZKGPU_ERR_DEGREE_LARGE, "PolynomialDegreeTooLarge");
+            take[j] = degree + 1;   // the coefficients above the degree are zero
+            total += take[j];
+        }
+        ctx->stage_b.reserve(total * sizeof(Fr));
+        const Fr *ptr[MsmEngine::MAX_BATCH];
+        size_t at = 0;
+        for (uint32_t j = 0; j < count; j++) {
+            Fr *dst = ctx->stage_b.as<Fr>() + at;
+            ZK_HIP(hipMemcpyAsync(dst, coeffs[j], take[j] * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+            ptr[j] = dst;
+            at += take[j];
+        }
+        G1Proj sums[MsmEngine::MAX_BATCH];
+        ctx->msm->msm_batch(count, ptr, take, 0, sums);
+        for (uint32_t j = 0; j < count; j++) affine_out(sums[j], out_xy + 12 * j, out_infinity ? out_infinity + j : nullptr);
+    });
+}
+
 int zkgpu_field_mul_selfcheck(int field, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out) {
     if ((field != 0 && field != 1) || ((!a || !b || !out) && count)) return ZKGPU_ERR_INVALID_ARG;
     for (size_t i = 0; i < count; i++) {

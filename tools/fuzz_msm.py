@@ -1,5 +1,6 @@
 """Randomised differential check of the MSM against the CPU oracle: small point sets with repeated and negated
-points, points at infinity, scalars that collide (equal, opposite, 0, 1, r - 1, small) and random window widths.
+points, points at infinity, scalars that collide (equal, opposite, 0, 1, r - 1, small) and random window widths; every
+case also as a ragged batch of up to four commitments (zkgpu_commit_many).
     python tools/fuzz_msm.py [ITERATIONS] [SEED]"""
 import os
 import sys
@@ -54,6 +55,30 @@ def main():
             print("MISMATCH at iteration", it, "seed", seed, "n", n, "window", window, "segment", seg)
             np.savez("gpurun_out/fuzz_fail.npz", pts=pts, inf=inf, sc=sc, window=window, seg=seg)
             sys.exit(1)
+        # the same scalars cut into a ragged batch of up to four commitments (one batched pass on the GPU)
+        m = int(rng.integers(2, 5))
+        polys, lens = [], []
+        for _ in range(m):
+            k = int(rng.integers(2, n + 1)) if n >= 2 else 0
+            if k < 2:
+                break
+            poly = sc[:k].copy()
+            if not poly[1:].any():
+                poly[k - 1] = M.fr_to_mont(3)          # degree at least one
+            polys.append(poly)
+            lens.append(k)
+        if polys:
+            try:
+                got = ctx.commit_many(polys)
+            except (zkvm_amd.ZkGpuError, ValueError) as e:
+                print("ERROR in commit_many at iteration", it, "seed", seed, "lens", lens, e)
+                sys.exit(1)
+            for j, poly in enumerate(polys):
+                top = max(i for i in range(lens[j]) if poly[i].any()) + 1
+                wx, wi = orc.g1_to_affine(orc.msm(pts[:top], poly[:top], inf=inf[:top], threads=4))
+                if got[j][1] != wi or not np.array_equal(got[j][0], wx):
+                    print("BATCH MISMATCH at iteration", it, "seed", seed, "lens", lens, "j", j, "window", window, "segment", seg)
+                    sys.exit(1)
         if it % 50 == 0:
             print("iteration", it, "ok", flush=True)
     ctx.msm_set_params(0, 0)

@@ -1064,8 +1064,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     ZK_HIP(hipMemsetAsync(class_cursor, 0, (size_t)m * (N_CLASSES + 1) * 4, stream_));
 
     if (profile_) ZK_HIP(hipEventRecord(profile_[0], stream_));
-    // per sum: digits and the count pass of its own items into its own B counters.  With one bucket range the
-    // launches are small and bound by latency, so each covers the whole batch.
+    // per sum: digits and the count pass of its own items into its own B counters
     SumArgs sums;
     SortGeom *geom = sums.g;
     uint32_t **dig = sums.dig;
@@ -1097,15 +1096,14 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     }
     const size_t part_stride = (size_t)B * S_max;
     uint32_t *const part_all = cursor_.as<uint32_t>();
-    const bool batched = n_ranges == 1 && m > 1;
-    const uint32_t n_launch = batched ? 1u : m, per_launch = batched ? m : 1u;
-    for (uint32_t j = 0; j < n_launch; j++) {
-        const size_t len_j = batched ? max_len : lens[j];
-        hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(len_j, 256), per_launch), dim3(256), 0, stream_, sums, j, c, K);
-        if (n_ranges == 1) {
-            hipLaunchKernelGGL(msm_sort_kernel<0>, dim3(batched ? S_used : geom[j].S, 1, per_launch), dim3(1024), lds_bytes, stream_,
-                               sums, j, part_all, part_stride, sorted_.as<uint32_t>());
-        } else {
+    // The small kernels (digits, totals, cursors, schedule, and the one-level sort) cover all sums of the batch in
+    // one launch each; the range partition and its sort run per sum.
+    hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(max_len, 256), m), dim3(256), 0, stream_, sums, 0u, c, K);
+    if (n_ranges == 1) {
+        hipLaunchKernelGGL(msm_sort_kernel<0>, dim3(S_used, 1, m), dim3(1024), lds_bytes, stream_, sums, 0u, part_all, part_stride,
+                           sorted_.as<uint32_t>());
+    } else {
+        for (uint32_t j = 0; j < m; j++) {
             uint32_t *part = part_all + (size_t)j * part_stride;
             const uint64_t n_items = geom[j].n_items;
             // range partition: count, scan (range-major, one extra entry = the total), place
@@ -1126,22 +1124,22 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             hipLaunchKernelGGL(msm_sort2_kernel<0>, dim3(geom[j].S * n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt, n_blocks,
                                geom[j], part, sorted_.as<uint32_t>());
         }
-        hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(B, 256), per_launch), dim3(256), 0, stream_, sums, j, part_all,
-                           part_stride, counts_.as<uint32_t>());
     }
+    hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(B, 256), m), dim3(256), 0, stream_, sums, 0u, part_all, part_stride,
+                       counts_.as<uint32_t>());
     // one scan over all m * B buckets: every bucket's run in `sorted`
     hipLaunchKernelGGL(scan_block_kernel, dim3(n_scan_blocks), dim3(256), 0, stream_, counts_.as<uint32_t>(),
                        offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream_, block_sums_.as<uint32_t>(), n_scan_blocks);
     hipLaunchKernelGGL(scan_finish_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, counts_.as<uint32_t>(),
                        offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb, big, tasks_.as<MsmTask>(), task_count, max_tasks);
-    for (uint32_t j = 0; j < n_launch; j++) {
-        hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(B, 256), per_launch), dim3(256), 0, stream_, sums, j, part_all,
-                           part_stride, offsets_.as<uint32_t>());
-        if (n_ranges == 1) {
-            hipLaunchKernelGGL(msm_sort_kernel<1>, dim3(batched ? S_used : geom[j].S, 1, per_launch), dim3(1024), lds_bytes, stream_,
-                               sums, j, part_all, part_stride, sorted_.as<uint32_t>());
-        } else {
+    hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(B, 256), m), dim3(256), 0, stream_, sums, 0u, part_all, part_stride,
+                       offsets_.as<uint32_t>());
+    if (n_ranges == 1) {
+        hipLaunchKernelGGL(msm_sort_kernel<1>, dim3(S_used, 1, m), dim3(1024), lds_bytes, stream_, sums, 0u, part_all, part_stride,
+                           sorted_.as<uint32_t>());
+    } else {
+        for (uint32_t j = 0; j < m; j++) {
             uint32_t *part = part_all + (size_t)j * part_stride;
             const uint32_t n_blocks = ceil_div(geom[j].n_items, RANGE_ITEMS);
             const uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
@@ -1150,14 +1148,12 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
                                n_blocks, geom[j], part, sorted_.as<uint32_t>());
         }
     }
-    // schedule (class histogram, scan, placement) per sum
-    for (uint32_t j = 0; j < n_launch; j++) {
-        hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024), per_launch), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
-                           class_shift, big, class_cursor, order, j);
-        hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(per_launch), dim3(64), 0, stream_, class_cursor, j);
-        hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024), per_launch), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
-                           class_shift, big, class_cursor, order, j);
-    }
+    // schedule: class histogram, scan, placement
+    hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024), m), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
+                       class_shift, big, class_cursor, order, 0u);
+    hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(m), dim3(64), 0, stream_, class_cursor, 0u);
+    hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024), m), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
+                       class_shift, big, class_cursor, order, 0u);
     if (profile_) ZK_HIP(hipEventRecord(profile_[1], stream_));
     // Up to 2^15 buckets per sum the launch is bound by the longest chain of additions on one lane, not by throughput:
     // the sums of a batch then share one launch, and two or four lanes share each bucket while the chains are worth

@@ -819,12 +819,18 @@ uint32_t MsmEngine::choose_window(size_t n) {
     double best_ms = 1e300;
     // 20 bits at most: beyond 2^19 buckets the sort's range count and the reduction grow faster than the model says
     // (measured at 2^24 points: 39 ms with 20 bits, 47 ms with 22)
-    for (uint32_t c = 4; c <= 20; c++) {
+    // Up to about 2^13 points 13 bits at most: the model is fitted to single sums, and in the batches of a proof the
+    // reduction over 2^15 buckets per sum costs more than it says (whole proofs: 2^12 gates 3.9 ms with 13 bits, 4.4
+    // with 16; 2^13: 4.3 against 4.6; 2^14: 5.6 against 4.8).
+    const uint32_t c_max = n < ((size_t)3 << 12) ? 13u : 20u;   // an SRS for 2^13 gates holds 2^13 + 7 points
+    for (uint32_t c = 4; c <= c_max; c++) {
         const uint32_t K = 255 / c + 1, top_bits = 255 - (K - 1) * c;
         const double B = (double)(1u << (c - 1)), items = (double)n * K, mean = items / B;
         const double log_b = (double)(c - 1);
-        double reduce = 0.20 + 0.0125 * ((log_b < 16 ? log_b : 16) > 7 ? (log_b < 16 ? log_b : 16) - 7 : 0);
-        if (B > 32768.0) reduce += 0.09;   // 8- or 16-bucket segments there, 4-bucket ones below
+        // ~0.2 ms of tree depth up to 2^12 buckets, +0.04 per doubling up to 2^15; above that 8- or 16-bucket segments
+        double reduce = 0.20;
+        if (log_b > 12) reduce += 0.04 * ((log_b < 15 ? log_b : 15) - 12);
+        if (log_b > 15) reduce += 0.09;
         if (B > 65536.0) reduce += (B - 65536.0) * 0.5e-6;
         // one-level sort (LDS counters for all buckets) up to 2^15 buckets, range partition + sort above
         const double sort = log_b <= 15 ? 0.03 + items * 80e-9 : 0.08 + items * 21e-9;
@@ -1002,7 +1008,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     const uint32_t max_tasks = (uint32_t)(total_items / big + total_items / BIG_CHUNK + m);
     const uint32_t n_scan_blocks = ceil_div(nb, SCAN_ITEMS);
     // segments of the bucket reduction: few buckets leave the chip idle, so short segments (shallow chains) win there
-    const uint32_t seg_bits = seg_bits_ ? seg_bits_ : (log_B <= 15 ? 2u : (m >= 3 ? 4u : 3u));
+    const uint32_t seg_bits = seg_bits_ ? seg_bits_ : (log_B <= 12 ? 1u : log_B <= 15 ? 2u : (m >= 3 ? 4u : 3u));
     const uint32_t log_seg = log_B < seg_bits ? log_B : seg_bits;
     const uint32_t segs_per_sum = 1u << (log_B - log_seg);
     const uint32_t n_bits = log_B - log_seg;
@@ -1162,7 +1168,9 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     // with one lane per bucket.
     const bool fused = log_B <= 15 && m > 1;
     uint32_t log_p = 0;
-    while (log_B <= 15 && log_p < 2 && (expect >> log_p) >= 6) log_p++;
+    uint64_t chain = max_items >> log_B;   // the fullest ordinary buckets: the mean plus their share of a short top window
+    if (top_bits < log_B) chain += (max_items / K) >> top_bits;
+    while (log_B <= 15 && log_p < 2 && (chain >> log_p) >= 6) log_p++;
     {
         const dim3 grid(ceil_div((uint64_t)B << log_p, 256), fused ? m : 1);
         for (uint32_t j = 0; j < (fused ? 1u : m); j++) {

@@ -54,7 +54,7 @@ class MsmEngine {
     size_t device_bytes() const;
     // Test hooks: window width used by the next load_points*, segment width of the bucket reduction.
     void set_window_override(uint32_t c) { window_override_ = c; }
-    // 0 = automatic: 4-bucket segments up to 2^15 buckets (bound by the depth of the chains), above that 8-bucket
+    // 0 = automatic: 2-bucket segments up to 2^12 buckets, 4-bucket ones up to 2^15 (bound by the depth of the chains), above that 8-bucket
     // segments, 16-bucket ones for batches of three or four sums (whose reduction is bound by work)
     void set_segment_bits(uint32_t b) { seg_bits_ = b; }
     uint32_t window_bits() const { return c_; }

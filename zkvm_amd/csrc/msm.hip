@@ -1162,7 +1162,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
                        class_shift, big, class_cursor, order, 0u);
     if (profile_) ZK_HIP(hipEventRecord(profile_[1], stream_));
     // Up to 2^15 buckets per sum the launch is bound by the longest chain of additions on one lane, not by throughput:
-    // the sums of a batch then share one launch, and two or four lanes share each bucket while the chains are worth
+    // the sums of a batch then share one launch, and two or more lanes share each bucket while the chains are worth
     // cutting (measured on 2^15-gate proofs: 8.8 ms with one lane per bucket and one launch per sum, 6.1 ms this way).
     // Larger bucket sets run one launch per sum (a single launch over all m * B buckets runs measurably slower there)
     // with one lane per bucket.
@@ -1170,7 +1170,8 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     uint32_t log_p = 0;
     uint64_t chain = max_items >> log_B;   // the fullest ordinary buckets: the mean plus their share of a short top window
     if (top_bits < log_B) chain += (max_items / K) >> top_bits;
-    while (log_B <= 15 && log_p < 2 && (chain >> log_p) >= 6) log_p++;
+    // four lanes at most unless the buckets are so few that even eight or sixteen lanes each leave the chip unfilled
+    while (log_B <= 15 && (chain >> log_p) >= 6 && (log_p < 2 || (log_p < 4 && ((uint64_t)m * B << log_p) < 65536))) log_p++;
     {
         const dim3 grid(ceil_div((uint64_t)B << log_p, 256), fused ? m : 1);
         for (uint32_t j = 0; j < (fused ? 1u : m); j++) {
@@ -1180,7 +1181,9 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             };
             if (log_p == 0) launch(msm_accumulate_kernel<0>);
             else if (log_p == 1) launch(msm_accumulate_kernel<1>);
-            else launch(msm_accumulate_kernel<2>);
+            else if (log_p == 2) launch(msm_accumulate_kernel<2>);
+            else if (log_p == 3) launch(msm_accumulate_kernel<3>);
+            else launch(msm_accumulate_kernel<4>);
         }
     }
     if (profile_) ZK_HIP(hipEventRecord(profile_[2], stream_));

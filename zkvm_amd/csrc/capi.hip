@@ -384,7 +384,14 @@ int zkgpu_commit_many(zkgpu_ctx *ctx, uint32_t count, const uint64_t *const *coe
         }
         G1Proj sums[MsmEngine::MAX_BATCH];
         ctx->msm->msm_batch(count, ptr, take, 0, sums);
-        for (uint32_t j = 0; j < count; j++) affine_out(sums[j], out_xy + 12 * j, out_infinity ? out_infinity + j : nullptr);
+        Fq xs[MsmEngine::MAX_BATCH], ys[MsmEngine::MAX_BATCH];
+        bool inf[MsmEngine::MAX_BATCH];
+        g1_to_affine_many(sums, count, xs, ys, inf);   // one inversion for the batch
+        for (uint32_t j = 0; j < count; j++) {
+            memcpy(out_xy + 12 * j, xs[j].v, 48);
+            memcpy(out_xy + 12 * j + 6, ys[j].v, 48);
+            if (out_infinity) out_infinity[j] = inf[j] ? 1 : 0;
+        }
     });
 }
 

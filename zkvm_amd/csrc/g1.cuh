@@ -151,4 +151,28 @@ FF_HD void g1_to_affine(const G1Proj &p, Fq &x, Fq &y, bool &infinity) {
     infinity = false;
 }
 
+// Affine forms of up to 8 projective points with a single field inversion (prefix products of the z coordinates,
+// one inverse, and back): the same canonical values as g1_to_affine point by point.
+inline void g1_to_affine_many(const G1Proj *p, uint32_t m, Fq *x, Fq *y, bool *infinity) {
+    Fq prefix[8];
+    Fq run = Fq::one();
+    for (uint32_t j = 0; j < m && j < 8; j++) {
+        infinity[j] = p[j].z.is_zero();
+        prefix[j] = run;
+        if (!infinity[j]) run = Fq::mul(run, p[j].z);
+    }
+    Fq inv = Fq::inv(run);
+    for (uint32_t j = (m < 8 ? m : 8); j-- > 0;) {
+        if (infinity[j]) {
+            x[j] = Fq::zero();
+            y[j] = Fq::one();
+            continue;
+        }
+        const Fq zinv = Fq::mul(inv, prefix[j]);
+        inv = Fq::mul(inv, p[j].z);
+        x[j] = Fq::mul(p[j].x, zinv);
+        y[j] = Fq::mul(p[j].y, zinv);
+    }
+}
+
 }  // namespace zk

@@ -141,7 +141,15 @@ int Prover::commit_many(uint32_t m, const Fr *const *coeffs, const uint64_t *len
             sums[j] = total;
         }
     }
-    for (uint32_t j = 0; j < m; j++) out[j] = to_affine(sums[j]);
+    // one inversion for the whole batch
+    Fq xs[MsmEngine::MAX_BATCH], ys[MsmEngine::MAX_BATCH];
+    bool inf[MsmEngine::MAX_BATCH];
+    g1_to_affine_many(sums, m, xs, ys, inf);
+    for (uint32_t j = 0; j < m; j++) {
+        out[j].x = xs[j];
+        out[j].y = ys[j];
+        out[j].infinity = inf[j];
+    }
     return 0;
 }
 

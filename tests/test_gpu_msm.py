@@ -141,6 +141,22 @@ def test_commit_many_ragged_batches(ctx, orc, n):
         ctx.commit_many([polys[0]] * 5)
 
 
+def test_window_width_by_table_size(orc):
+    """The measured choices of the window model: 13-bit windows up to an SRS for 2^13 gates, 16 bits up to 2^17
+    points, 20 above (and never more: 22 bits at 2^24 points was 20 % slower)."""
+    import zkvm_amd
+    from zkvm_amd import circuits
+    c = zkvm_amd.Context(0)
+    try:
+        for n, want in ((1 << 10, 13), ((1 << 13) + 7, 13), ((1 << 14) + 7, 16), ((1 << 17) + 7, 16), ((1 << 18) + 7, 20),
+                        ((1 << 20) + 7, 20)):
+            c.srs_setup(circuits.seeded_tau(), circuits.g1_generator_limbs(), n)
+            bits, levels = c.msm_get_params()
+            assert (bits, levels) == (want, 255 // want + 1), n
+    finally:
+        c.close()
+
+
 def test_msm_2_16_device_scalars_and_sharding(ctx, orc):
     """65536 distinct points (tau-powers SRS), scalars resident in HBM; the two half-range partial sums add up to
     the full result (the point-range sharding used across GPUs)."""

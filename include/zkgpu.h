@@ -11,8 +11,11 @@
  *                   G1Affine::to_raw_bytes() (coset-bls12_381/src/g1/coset.rs:8-24); the infinity flag travels
  *                   as a separate byte
  * Every function returns 0 on success and a negative ZKGPU_ERR_* code otherwise; zkgpu_last_error() then
- * holds a message.  Nothing throws or aborts across this boundary.  Calls on one context are serialised by
- * the caller (one context per thread or an external lock); different contexts are independent.
+ * holds a message.  Nothing throws or aborts across this boundary.  A context may be shared by several host
+ * threads, as the reference's Prover::prove takes &self (plonk/src/compiler/prover.rs:21,210): every call locks the
+ * context for its duration, so calls on one context run one after the other; different contexts are independent and
+ * run concurrently (each has its own stream and buffers).  zkgpu_last_error returns the calling thread's own last
+ * failure on that context.
  */
 #ifndef ZKGPU_H
 #define ZKGPU_H

@@ -405,7 +405,10 @@ struct Proof {
 
 // widget.rs:199-228 (VerifierKey::seed_transcript) on top of transcript.rs:51-65 (Transcript::base).
 // comms are in Sel order; zero selector polynomials commit to the identity (compiler.rs:152-166).
-static inline Transcript transcript_base(const std::string &label, const G1Affine comms[N_SEL], uint64_t constraints) {
+// `vk_n` is VerifierKey.n, which seed_transcript appends last (widget.rs:227); Compiler::preprocess sets it to the
+// constraint count (compiler.rs:211-212), a deserialized key carries its own (widget.rs:102-106).
+static inline Transcript transcript_base(const std::string &label, const G1Affine comms[N_SEL], uint64_t constraints,
+                                         uint64_t vk_n) {
     Transcript t(label);
     t.circuit_domain_sep(constraints);
     static const struct {
@@ -418,7 +421,7 @@ static inline Transcript transcript_base(const std::string &label, const G1Affin
                  {"s_sigma_1", S1},    {"s_sigma_2", S2},    {"s_sigma_3", S3},
                  {"s_sigma_4", S1}};  // sic: widget.rs:224-225 appends s_sigma_1 under the label "s_sigma_4"
     for (auto &o : order) t.append_commitment(o.label, comms[o.sel]);
-    t.circuit_domain_sep(constraints);
+    t.circuit_domain_sep(vk_n);
     return t;
 }
 
@@ -428,6 +431,7 @@ struct Prover {  // prover.rs:22-30
     G1Affine selector_comms[N_SEL];
     std::string label;
     size_t size, constraints;
+    uint64_t vk_n = 0;   // VerifierKey.n; equals `constraints` for a compiled prover (compiler.rs:211-212)
     std::vector<size_t> public_input_indexes;
 
     // compiler.rs:152-171: unwrap_or_default for the 11 selectors, `?` for the sigmas
@@ -462,7 +466,7 @@ static inline int prove(const Prover &pr, const FrVec wires[4], const FrVec &pub
                         Proof &proof, unsigned n_threads = 1, std::vector<Fr> *challenges_out = nullptr) {
     const Fr *bl = blinders_in;
     EvaluationDomain domain(pr.constraints);
-    Transcript transcript = transcript_base(pr.label, pr.selector_comms, pr.constraints);
+    Transcript transcript = transcript_base(pr.label, pr.selector_comms, pr.constraints, pr.vk_n);
     FrVec dense(pr.size, fr_zero());  // composer.rs:1001-1014
     for (size_t i = 0; i < pr.public_input_indexes.size() && i < public_inputs.size(); i++)
         dense[pr.public_input_indexes[i]] = public_inputs[i];
@@ -575,7 +579,7 @@ static inline int prove(const Prover &pr, const FrVec wires[4], const FrVec &pub
 // Returns beta gamma alpha range logic fixed var z v v_w u.
 static inline std::vector<Fr> verifier_challenges(const std::string &label, const G1Affine comms[N_SEL], uint64_t constraints,
                                                   const FrVec &public_inputs, const Proof &proof) {
-    Transcript t = transcript_base(label, comms, constraints);
+    Transcript t = transcript_base(label, comms, constraints, constraints);
     for (auto &pi : public_inputs) t.append_scalar("pi", pi);
     t.append_commitment("a_comm", proof.a_comm);
     t.append_commitment("b_comm", proof.b_comm);
@@ -689,10 +693,11 @@ static inline std::vector<uint8_t> prover_key_to_var_bytes(const ProverKey &pk) 
     w.write(vb.data(), vb.size());
     return bytes;
 }
-// VerifierKey::to_bytes (widget.rs:73-100): n = the constraint count (compiler.rs:211-212), 15 compressed points
-static inline std::vector<uint8_t> verifier_key_to_bytes(uint64_t constraints, const G1Affine comms[N_SEL]) {
+// VerifierKey::to_bytes (widget.rs:73-100): n (the constraint count for a compiled key, compiler.rs:211-212), 15
+// compressed points
+static inline std::vector<uint8_t> verifier_key_to_bytes(uint64_t vk_n, const G1Affine comms[N_SEL]) {
     std::vector<uint8_t> out(8 + 48 * N_SEL);
-    for (int i = 0; i < 8; i++) out[i] = (uint8_t)(constraints >> (8 * i));
+    for (int i = 0; i < 8; i++) out[i] = (uint8_t)(vk_n >> (8 * i));
     for (int j = 0; j < N_SEL; j++) g1a_to_compressed(comms[SERIAL_ORDER[j]], out.data() + 8 + 48 * j);
     return out;
 }
@@ -708,7 +713,7 @@ static inline std::vector<uint8_t> commit_key_to_raw_var_bytes(const CommitKey &
 // lengths, size, constraints), then the four pieces
 static inline std::vector<uint8_t> prover_to_bytes(const Prover &pr) {
     std::vector<uint8_t> pk = prover_key_to_var_bytes(pr.pk), ck = commit_key_to_raw_var_bytes(pr.ck),
-                         vk = verifier_key_to_bytes(pr.constraints, pr.selector_comms);
+                         vk = verifier_key_to_bytes(pr.vk_n, pr.selector_comms);
     std::vector<uint8_t> out;
     out.reserve(48 + pr.label.size() + pk.size() + ck.size() + vk.size());
     put_u64be(out, pr.label.size());

@@ -380,6 +380,10 @@ class Prover:
                                     C.c_size_t(pi.shape[0]), _p(out))
         return out[:k].copy()
 
+    def set_vk_n(self, vk_n):
+        """VerifierKey.n of a prover rebuilt from bytes (widget.rs:102-106); a compiled prover has n = constraints."""
+        lib().orc_prover_set_vk_n(self._h, C.c_uint64(vk_n))
+
     def to_bytes(self):
         """Prover::to_bytes (compiler/prover.rs:109-134) as a numpy uint8 array"""
         size = lib().orc_prover_to_bytes(self._h, None, C.c_size_t(0))

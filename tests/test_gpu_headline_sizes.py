@@ -1,0 +1,172 @@
+"""GPU parity at the sizes the benchmark is quoted on, bit for bit against the CPU oracle on raw limbs: a 2^20-point
+commitment over a real tau-power SRS (uniform and witness-like scalars), the 2^23-point coset transforms of the quotient,
+one whole 2^20-gate proof, and - where the oracle would need minutes - the 2^24-point commitment through properties of
+the group.  The oracle legs run for tens of seconds each (the reference's FFT is serial, its MSM window-parallel)."""
+import numpy as np
+import pytest
+
+import model as M
+
+pytestmark = pytest.mark.gpu
+
+LOG_N = 20
+N = 1 << LOG_N
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import zkvm_amd
+    c = zkvm_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def srs20(ctx, orc):
+    """SRS of a 2^20-gate circuit (2^20 + 7 powers of tau times G), generated on the GPU, exported, and pinned
+    independently of the library: the first powers by the oracle's PublicParameters::setup restatement, scattered ones
+    by big-integer scalar multiplication."""
+    tau = M.random_fr_mont(1, seed=2020)[0]
+    g = orc.g1_generator()
+    gxy, _ = orc.g1_to_affine(g)
+    ctx.srs_setup(tau, gxy, N + 7)
+    xy, inf = ctx.srs_export(N + 7)
+    assert not inf.any()
+    want_xy, want_inf = orc.srs_powers(g, tau, 48)
+    assert np.array_equal(xy[:48], want_xy) and not want_inf.any()
+    tau_int = M.fr_from_mont(tau)
+    g_aff = M.affine_from_limbs(gxy)
+    for i in (1 << 10, (1 << 19) + 12345, N - 1, N + 6):
+        assert M.affine_from_limbs(xy[i]) == M.ec_mul(g_aff, pow(tau_int, i, M.R_MOD)), i
+    return dict(tau=tau, gxy=gxy, xy=xy)
+
+
+def witness_like(n, seed):
+    """30 % zeros, 20 % ones, 20 % below 2^16, 30 % uniform: the shape of a wire column (values in Montgomery form,
+    so the digits the bucket method sees are those of 0, 1 and the small integers themselves)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sc = M.random_fr_mont(n, seed)
+    kind = rng.random(n)
+    sc[kind < 0.3] = 0
+    sc[(kind >= 0.3) & (kind < 0.5)] = M.fr_to_mont(1)
+    mask = (kind >= 0.5) & (kind < 0.7)
+    sc[mask] = M.fr_vec_to_mont([int(v) for v in rng.integers(0, 1 << 16, size=int(mask.sum()))])
+    return sc
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kind", ["uniform", "witness_like"])
+def test_msm_2_20_on_tau_power_srs(ctx, orc, srs20, kind):
+    """multiscalar_mul.rs:143-220 + commitment.rs:34-38 at 2^20 points: every limb of the affine sum."""
+    import torch
+    if kind == "uniform":
+        sc = M.random_fr_mont(N, 3)
+    else:
+        sc = witness_like(N, 4)
+    sd = torch.from_numpy(sc.view(np.int64)).cuda()
+    got_xy, got_inf = ctx.msm(sd)
+    want_xy, want_inf = orc.g1_to_affine(orc.msm(srs20["xy"][:N], sc, threads=16))
+    assert got_inf == int(want_inf) and np.array_equal(got_xy, want_xy)
+    # the host-pointer entry point and the commitment of the same coefficients agree
+    xy2, inf2 = ctx.commit(sc)
+    assert inf2 == got_inf and np.array_equal(xy2, got_xy)
+
+
+@pytest.mark.timeout(600)
+def test_coset_transforms_2_23_match_oracle(ctx, orc):
+    """fft/domain.rs:176-196 on the 8n domain of a 2^20-gate circuit: coset_fft of an (n+3)-coefficient polynomial and
+    coset_ifft of a full vector, all 2^23 outputs."""
+    import torch
+    n8 = 8 * N
+    coeffs = M.random_fr_mont(N + 3, 2)
+    ev = ctx.ntt(torch.from_numpy(coeffs.view(np.int64)).cuda(), LOG_N + 3, 2)
+    ctx.sync()
+    want = orc.fft("coset_fft", coeffs, n8)
+    assert np.array_equal(ev.cpu().numpy().view(np.uint64), want)
+    del ev
+    full = M.random_fr_mont(n8, 23)
+    back = ctx.ntt(torch.from_numpy(full.view(np.int64)).cuda(), LOG_N + 3, 3)
+    ctx.sync()
+    assert np.array_equal(back.cpu().numpy().view(np.uint64), orc.fft("coset_ifft", full, n8))
+
+
+@pytest.mark.timeout(900)
+def test_prove_2_20_equals_oracle_proof(ctx, orc, srs20):
+    """compiler/prover.rs:210-509 at the headline size: the 11 commitments, 15 evaluations and 10 challenges of the GPU
+    proof against the oracle's on the same circuit, SRS and blinders."""
+    import torch
+    from zkvm_amd import api, circuits
+    c = circuits.arithmetic_circuit(N, seed=20)
+    c["selectors"][11:15] = np.stack([orc.sigma_to_lagrange(c["sigma_map"][k]) for k in range(4)])
+    # srs20 left the context holding this SRS
+    gp = api.Prover(ctx, N, c["constraints"], c["selectors"].reshape(-1, 4), b"headline", c["pi_indexes"])
+    bl = circuits.random_blinders(20)
+    wires = torch.from_numpy(c["wires"].reshape(-1, 4).view(np.int64)).cuda()
+    got = gp.prove(wires, c["public_inputs"], bl)
+    del wires
+    op = orc.Prover(N, c["constraints"], c["selectors"], srs20["xy"], b"headline", c["pi_indexes"], threads=16)
+    assert op.preprocess_rc == 0
+    sxy, sinf = gp.selector_commitments()
+    wxy, winf = op.selector_comms()
+    assert np.array_equal(sinf, winf) and np.array_equal(sxy, wxy)
+    c["selectors"] = None
+    want = op.prove(c["wires"], c["public_inputs"], bl)
+    assert want["rc"] == 0
+    for key in ("challenges", "evals", "comms_inf", "comms"):
+        assert np.array_equal(got[key], want[key]), key
+
+
+def negate_mont(sc):
+    """limb-wise r - s on Montgomery residues (negation commutes with the Montgomery map); zero stays zero"""
+    n = sc.shape[0]
+    r_limbs = np.array([0xffffffff00000001, 0x53bda402fffe5bfe, 0x3339d80809a1d805, 0x73eda753299d7d48], dtype=np.uint64)
+    neg = np.zeros_like(sc)
+    borrow = np.zeros(n, dtype=np.uint64)
+    for k in range(4):
+        a = np.full(n, r_limbs[k], dtype=np.uint64)
+        t = a - sc[:, k]
+        b1 = (a < sc[:, k]).astype(np.uint64)
+        t2 = t - borrow
+        b2 = (t < borrow).astype(np.uint64)
+        neg[:, k] = t2
+        borrow = b1 | b2
+    neg[(sc == 0).all(axis=1)] = 0
+    return neg
+
+
+@pytest.mark.timeout(600)
+def test_msm_2_24_distinct_points_properties(orc):
+    """The largest commitment the reference's configurations name: 2^24 distinct tau-powers.  The oracle needs minutes
+    there, so the sum is checked through the group: unequal range shards add up to the whole, a 2^16-point slice of it
+    equals the oracle's sum over the exported points, and the sums over s and r - s cancel."""
+    import torch
+    import zkvm_amd
+    from zkvm_amd import circuits
+    n = 1 << 24
+    c = zkvm_amd.Context(0)
+    try:
+        c.srs_setup(circuits.seeded_tau(), circuits.g1_generator_limbs(), n)
+        sc = M.random_fr_mont(n, seed=2424)
+        sc[:5] = 0
+        sd = torch.from_numpy(sc.view(np.int64)).cuda()
+        whole = c.msm_partial(sd, 0)
+        xy, inf = zkvm_amd.g1_sum_to_affine(whole.reshape(1, 18))
+        assert inf == 0
+        cuts = [0, 3_000_017, (1 << 23) + 5, 13_000_000, n]
+        parts = np.stack([c.msm_partial(sd[cuts[k]:cuts[k + 1]].contiguous(), cuts[k]) for k in range(4)])
+        xy2, inf2 = zkvm_amd.g1_sum_to_affine(parts)
+        assert inf2 == 0 and np.array_equal(xy, xy2)
+        # one slice against the oracle, on the points as exported
+        lo, m = cuts[2], 1 << 16
+        pts, pinf = c.srs_export(lo + m)
+        assert not pinf.any()
+        slice_part = c.msm_partial(sd[lo:lo + m].contiguous(), lo)
+        sxy, sinf = zkvm_amd.g1_sum_to_affine(slice_part.reshape(1, 18))
+        wxy, winf = orc.g1_to_affine(orc.msm(pts[lo:], sc[lo:lo + m], threads=16))
+        assert sinf == int(winf) and np.array_equal(sxy, wxy)
+        del pts
+        other = c.msm_partial(torch.from_numpy(negate_mont(sc).view(np.int64)).cuda(), 0)
+        _, inf3 = zkvm_amd.g1_sum_to_affine(np.stack([whole, other]))
+        assert inf3 == 1
+    finally:
+        c.close()

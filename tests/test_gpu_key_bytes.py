@@ -66,6 +66,30 @@ def test_to_bytes_matches_oracle_and_round_trips(ctx, orc, log_n, seed):
         assert np.array_equal(out[key], ref[key]), key
 
 
+def test_verifier_key_n_differs_from_the_header(ctx, orc):
+    """The serialized VerifierKey carries its own n (widget.rs:102-106), which closes the transcript seed
+    (widget.rs:227), while the first separator takes the header's constraint count (transcript.rs:60): bytes whose two
+    values differ must prove like the reference's deserialized prover, and be written back unchanged."""
+    from zkvm_amd import api, circuits
+    n = 1 << 6
+    c = _circuit(orc, n, 71)
+    srs = _srs(orc, n + 7)
+    op = orc.Prover(n, c["constraints"], c["selectors"], srs, b"vk-n", c["pi_indexes"], threads=4)
+    bl = circuits.random_blinders(71)
+    plain = op.prove(c["wires"], c["public_inputs"], bl)
+    op.set_vk_n(c["constraints"] + 5)
+    blob = op.to_bytes()
+    vk_at = blob.size - (8 + 48 * 15)
+    assert int.from_bytes(bytes(blob[vk_at:vk_at + 8]), "little") == c["constraints"] + 5
+    ref = op.prove(c["wires"], c["public_inputs"], bl)
+    assert not np.array_equal(ref["challenges"], plain["challenges"])     # the seed really changed
+    lp = api.Prover.try_from_bytes(ctx, blob, c["pi_indexes"])
+    out = lp.prove(c["wires"].reshape(-1, 4), c["public_inputs"], bl)
+    for key in ("challenges", "evals", "comms_inf", "comms"):
+        assert np.array_equal(out[key], ref[key]), key
+    assert np.array_equal(lp.to_bytes(), blob)
+
+
 def test_malformed_bytes_are_rejected(ctx, orc):
     import zkvm_amd
     from zkvm_amd import api

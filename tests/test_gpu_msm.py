@@ -180,6 +180,22 @@ def test_msm_2_16_device_scalars_and_sharding(ctx, orc):
     assert inf == want_inf and np.array_equal(xy, want_xy)
 
 
+def test_partial_range_arguments_cannot_wrap(ctx, orc):
+    """A huge base must be refused as an argument error, not wrap around the range check and index past the table."""
+    import ctypes as C
+    import torch
+    import zkvm_amd
+    pts, _ = orc.g1_multiples_of_generator(1, 64)
+    ctx.srs_load(pts)
+    sd = torch.from_numpy(M.random_fr_mont(64, 5).view(np.int64)).cuda()
+    out = np.zeros(18, dtype=np.uint64)
+    size_max = C.c_size_t(-1).value
+    for n, base in ((2, size_max - 1), (64, size_max - 63), (1, 64), (65, 0), (2, 63)):
+        rc = ctx._lib.zkgpu_msm_partial_dev(ctx._h, sd.data_ptr(), n, base, out.ctypes.data)
+        assert rc == -1, (n, base)
+    assert ctx._lib.zkgpu_msm_partial_dev(ctx._h, sd.data_ptr(), 1, 63, out.ctypes.data) == 0
+
+
 def test_msm_repeated_scalars_default_window(ctx, orc):
     """Runs of equal scalars give buckets from a few entries to thousands on every level: below the oversize
     threshold they stay with one thread, above it they are split into workgroup tasks (one and several chunks)."""

@@ -173,6 +173,49 @@ def test_prove_twice_same_key(ctx, orc, srs):
         assert np.array_equal(got["comms"], want["comms"]) and np.array_equal(got["evals"], want["evals"])
 
 
+def test_two_host_threads_share_one_context(ctx, orc, srs):
+    """Prover::prove takes &self (compiler/prover.rs:21,210): several host threads may prove with one prover.  The
+    library serialises calls on a context, so concurrent proofs and transforms on one context stay exact."""
+    import threading
+    from zkvm_amd import circuits
+    c = _circuit(orc, 512, seed=14)
+    gp, op = _provers(ctx, orc, srs, c)
+    blinders = [circuits.random_blinders(s) for s in range(4)]
+    wants = [op.prove(c["wires"], c["public_inputs"], bl) for bl in blinders]
+    x = M.random_fr_mont(1 << 12, 15)
+    want_fft = orc.fft("coset_fft", x, 1 << 12)
+    results, errors = {}, []
+
+    def prove_worker(t):
+        try:
+            for rep in range(3):
+                for k in (t, t + 2):
+                    results[(t, rep, k)] = gp.prove(c["wires"].reshape(-1, 4), c["public_inputs"], blinders[k])
+        except Exception as e:   # surfaced below: an exception in a thread would otherwise be lost
+            errors.append(e)
+
+    def ntt_worker():
+        try:
+            for rep in range(20):
+                results[("ntt", rep)] = ctx.ntt(x, 12, 2)
+        except Exception as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=prove_worker, args=(t,)) for t in (0, 1)] + [threading.Thread(target=ntt_worker)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for (key, got) in results.items():
+        if key[0] == "ntt":
+            assert np.array_equal(got, want_fft)
+        else:
+            want = wants[key[2]]
+            for f in ("challenges", "evals", "comms_inf", "comms"):
+                assert np.array_equal(got[f], want[f]), (key, f)
+
+
 def test_prove_unsatisfied_circuit(ctx, orc, srs):
     """A witness violating a gate leaves a quotient of 8n coefficients; its fourth slice exceeds the SRS and the
     reference's commit returns PolynomialDegreeTooLarge (kzg10/key.rs:91-105)."""

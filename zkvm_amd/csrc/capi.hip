@@ -24,31 +24,50 @@ struct zkgpu_ctx {
     DevBuf stage_a, stage_b;  // staging for the host-pointer entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string last_error;
+    // Calls on one context are serialised here: the reference's Prover::prove takes &self and may be called from
+    // several threads (plonk/src/compiler/prover.rs:21,210), while a context owns one stream and one set of buffers.
+    std::recursive_mutex lock;
 };
 
 static thread_local std::string g_init_error;
+static thread_local std::string t_error;                 // message of this thread's last failing call on t_error_ctx
+static thread_local const zkgpu_ctx *t_error_ctx = nullptr;
 
-// Runs `body`, mapping exceptions to error codes; never lets one cross the C boundary.
+// Runs `body`, mapping exceptions to error codes and leaving the message in `err`; never lets one cross the C
+// boundary.
 template <class F>
-static int guarded(zkgpu_ctx *ctx, F body) {
-    if (!ctx) return ZKGPU_ERR_INVALID_ARG;
+static int no_throw(std::string &err, F body) {
     try {
-        ZK_HIP(hipSetDevice(ctx->device));
         body();
         return ZKGPU_OK;
     } catch (const ZkError &e) {
-        ctx->last_error = e.what();
+        err = e.what();
         return e.code;
     } catch (const std::bad_alloc &) {
-        ctx->last_error = "host allocation failed";
+        err = "host allocation failed";
         return ZKGPU_ERR_OOM;
     } catch (const std::exception &e) {
-        ctx->last_error = e.what();
+        err = e.what();
         return ZKGPU_ERR_INTERNAL;
     } catch (...) {
-        ctx->last_error = "unknown error";
+        err = "unknown error";
         return ZKGPU_ERR_INTERNAL;
     }
+}
+// The same for a call on a context, holding the context's lock for the whole call.
+template <class F>
+static int guarded(zkgpu_ctx *ctx, F body) {
+    if (!ctx) return ZKGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::recursive_mutex> hold(ctx->lock);
+    const int rc = no_throw(ctx->last_error, [&] {
+        ZK_HIP(hipSetDevice(ctx->device));
+        body();
+    });
+    if (rc != ZKGPU_OK) {   // the calling thread's own copy: another thread's failure cannot overwrite it
+        t_error = ctx->last_error;
+        t_error_ctx = ctx;
+    }
+    return rc;
 }
 
 static void fr_to_u64(const Fr &a, uint64_t out[4]) { memcpy(out, a.v, 32); }
@@ -78,9 +97,12 @@ int zkgpu_init(zkgpu_ctx **out, int device_id) {
         return ZKGPU_ERR_INVALID_ARG;
     }
     zkgpu_ctx *ctx = new (std::nothrow) zkgpu_ctx();
-    if (!ctx) return ZKGPU_ERR_OOM;
+    if (!ctx) {
+        g_init_error = "host allocation failed";
+        return ZKGPU_ERR_OOM;
+    }
     ctx->device = device_id;
-    try {
+    const int rc = no_throw(g_init_error, [&] {
         ZK_HIP(hipSetDevice(device_id));
         ZK_HIP(hipStreamCreate(&ctx->stream));
         ZK_HIP(hipEventCreate(&ctx->ev0));
@@ -89,11 +111,10 @@ int zkgpu_init(zkgpu_ctx **out, int device_id) {
         ctx->msm.reset(new MsmEngine(ctx->stream));
         ctx->poly.reset(new PolyEngine(ctx->stream));
         ctx->prover.reset(new Prover(ctx->stream, *ctx->ntt, *ctx->msm, *ctx->poly));
-    } catch (const ZkError &err) {
-        g_init_error = err.what();
-        int code = err.code;
-        delete ctx;
-        return code;
+    });
+    if (rc != ZKGPU_OK) {
+        zkgpu_destroy(ctx);   // releases whatever was created: engines, events, stream
+        return rc;
     }
     *out = ctx;
     return ZKGPU_OK;
@@ -101,6 +122,7 @@ int zkgpu_init(zkgpu_ctx **out, int device_id) {
 
 void zkgpu_destroy(zkgpu_ctx *ctx) {
     if (!ctx) return;
+    if (t_error_ctx == ctx) t_error_ctx = nullptr;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->prover.reset();
@@ -115,7 +137,11 @@ void zkgpu_destroy(zkgpu_ctx *ctx) {
     delete ctx;
 }
 
-const char *zkgpu_last_error(const zkgpu_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_init_error.c_str(); }
+const char *zkgpu_last_error(const zkgpu_ctx *ctx) {
+    if (!ctx) return g_init_error.c_str();
+    if (ctx == t_error_ctx) return t_error.c_str();
+    return ctx->last_error.c_str();
+}
 
 int zkgpu_sync(zkgpu_ctx *ctx) {
     return guarded(ctx, [&] { ZK_HIP(hipStreamSynchronize(ctx->stream)); });
@@ -141,7 +167,7 @@ int zkgpu_timer_stop(zkgpu_ctx *ctx, float *elapsed_ms) {
 
 int zkgpu_domain_new(uint64_t num_coeffs, zkgpu_domain *out) {
     if (!out) return ZKGPU_ERR_INVALID_ARG;
-    try {
+    return no_throw(g_init_error, [&] {
         Domain d = Domain::make(num_coeffs);
         out->size = d.size;
         out->log_size_of_group = d.log_size;
@@ -150,11 +176,7 @@ int zkgpu_domain_new(uint64_t num_coeffs, zkgpu_domain *out) {
         fr_to_u64(d.group_gen, out->group_gen);
         fr_to_u64(d.group_gen_inv, out->group_gen_inv);
         fr_to_u64(d.generator_inv, out->generator_inv);
-        return ZKGPU_OK;
-    } catch (const ZkError &e) {
-        g_init_error = e.what();
-        return e.code;
-    }
+    });
 }
 
 int zkgpu_ntt_dev(zkgpu_ctx *ctx, const void *in_dev, size_t len_in, void *out_dev, uint32_t log_n, int mode) {
@@ -276,7 +298,9 @@ int zkgpu_msm_partial_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, siz
     return guarded(ctx, [&] {
         ZK_REQUIRE(out_xyz != nullptr, ZKGPU_ERR_INVALID_ARG, "msm: null output");
         ZK_REQUIRE(scalars_dev != nullptr || n == 0, ZKGPU_ERR_INVALID_ARG, "msm: null scalars");
-        ZK_REQUIRE(base + n <= ctx->msm->n_points(), ZKGPU_ERR_INVALID_ARG, "msm: point range outside the loaded SRS");
+        // written so that a huge base cannot wrap the sum
+        ZK_REQUIRE(n <= ctx->msm->n_points() && base <= ctx->msm->n_points() - n, ZKGPU_ERR_INVALID_ARG,
+                   "msm: point range outside the loaded SRS");
         G1Proj sum = n ? ctx->msm->msm(static_cast<const Fr *>(scalars_dev), n, base) : G1Proj::identity();
         memcpy(out_xyz, sum.x.v, 48);
         memcpy(out_xyz + 6, sum.y.v, 48);
@@ -438,6 +462,7 @@ int zkgpu_g1_bucket_selfcheck(const uint64_t *xy, const uint8_t *infinity, const
 int zkgpu_g1_bucket_selfcheck_tree(const uint64_t *xy, const uint8_t *infinity, const uint8_t *negate, size_t n,
                                    uint64_t out_xyz[18], uint64_t *violations) {
     if ((!xy && n) || !out_xyz) return ZKGPU_ERR_INVALID_ARG;
+    return no_throw(g_init_error, [&] {
     const long before = fq28_violations();
     std::vector<G1Xyzz> level(n ? n : 1, G1Xyzz::identity());
     for (size_t i = 0; i < n; i++) {
@@ -456,7 +481,7 @@ int zkgpu_g1_bucket_selfcheck_tree(const uint64_t *xy, const uint8_t *infinity, 
     G1Proj r = xyzz_to_proj(level[0]);
     memcpy(out_xyz, &r, sizeof r);
     if (violations) *violations = (uint64_t)(fq28_violations() - before);
-    return ZKGPU_OK;
+    });
 }
 
 int zkgpu_g1_compress(const uint64_t xy[12], uint8_t infinity, uint8_t out[48]) {
@@ -663,6 +688,10 @@ int zkgpu_prove(zkgpu_ctx *ctx, const uint64_t *wires, const uint64_t *public_in
         if (out_challenges10) memcpy(out_challenges10, proof.challenges, sizeof proof.challenges);
         if (timings8) memcpy(timings8, tm.ms, sizeof tm.ms);
     });
+    if (rc == 0 && proof_rc != 0) {
+        t_error = ctx->last_error;
+        t_error_ctx = ctx;
+    }
     return rc != 0 ? rc : proof_rc;
 }
 

@@ -982,7 +982,8 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     const uint32_t nb = m * B;   // bucket j * B + b belongs to sum j
     uint64_t total_items = 0, max_items = 0;
     for (uint32_t j = 0; j < m; j++) {
-        ZK_REQUIRE(base + lens[j] <= n_points_, ZKGPU_ERR_INVALID_ARG, "msm: more scalars than loaded points");
+        ZK_REQUIRE(lens[j] <= n_points_ && base <= n_points_ - lens[j], ZKGPU_ERR_INVALID_ARG,
+                   "msm: more scalars than loaded points");
         ZK_REQUIRE(lens[j] >= 1 && lens[j] < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "msm: bad length");
         total_items += (uint64_t)lens[j] * K;
         if ((uint64_t)lens[j] * K > max_items) max_items = (uint64_t)lens[j] * K;

@@ -243,6 +243,7 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
     n_ = n;
     log_n_ = log_n;
     constraints_ = constraints;
+    vk_n_ = constraints;   // compiler.rs:211-212
     label_ = label;
     pi_indexes_.assign(pi_indexes, pi_indexes + n_pi);
     widgets_ = 0;
@@ -443,6 +444,7 @@ void Prover::load_key_bytes(const uint8_t *b, size_t len, const uint64_t *pi_ind
     ZK_REQUIRE(canonical, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: a scalar is not below the field modulus");
     n_ = n;
     constraints_ = constraints;
+    vk_n_ = rd_le64(vk);   // VerifierKey::from_bytes keeps the stored n (widget.rs:102-106)
     label_.assign(reinterpret_cast<const char *>(label), label_len);
     pi_indexes_.assign(pi_indexes, pi_indexes + n_pi);
     widgets_ = 0;
@@ -552,7 +554,7 @@ size_t Prover::to_bytes(uint8_t *out, size_t cap) {
     uint8_t *ck = pk + pk_size;
     msm_.export_points_raw(ck);
     uint8_t *vk = ck + ck_size;
-    wr_le64(vk, constraints_);
+    wr_le64(vk, vk_n_);
     for (int j = 0; j < N_SEL; j++) {
         const AffineOut &c = sel_comms_[SERIAL_ORDER[j]];
         uint64_t xy[12];
@@ -706,7 +708,7 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
                      {"q_logic", Q_LOGIC}, {"q_variable_group_add", Q_VAR}, {"q_fixed_group_add", Q_FIXED},
                      {"s_sigma_1", S1},    {"s_sigma_2", S2},    {"s_sigma_3", S3}, {"s_sigma_4", S1}};
         for (auto &o : order) tr.append_commitment(o.label, sel_comms_[o.sel]);
-        tr.circuit_domain_sep(constraints_);
+        tr.circuit_domain_sep(vk_n_);   // widget.rs:227: the verifier key's own n
     }
     for (auto &pi : public_inputs) tr.append_scalar("pi", pi);  // prover.rs:236-238
 

@@ -89,6 +89,8 @@ class Prover {
     uint32_t world_ = 1;
     uint32_t n_ = 0, log_n_ = 0;
     uint64_t constraints_ = 0;
+    uint64_t vk_n_ = 0;   // VerifierKey.n: the constraint count for a compiled key (compiler.rs:211-212), the stored value
+                          // for one loaded from bytes (widget.rs:102-106); closes the transcript seed (widget.rs:227)
     std::string label_;
     std::vector<uint64_t> pi_indexes_;
     uint64_t poly_len_[N_SEL] = {0};

@@ -88,6 +88,18 @@ int zkgpu_ntt(zkgpu_ctx *ctx, uint64_t *data, size_t len_in, uint32_t log_n, int
  * out_dev must hold 2^log_n elements. */
 int zkgpu_ntt_dev(zkgpu_ctx *ctx, const void *in_dev, size_t len_in, void *out_dev, uint32_t log_n, int mode);
 
+/* zkgpu_ntt_dev for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  It calls no hipMalloc / hipFree and no allocating routine of
+ * any library: the buffer between the passes of the transform is a file-scope device array of
+ * 2^ZKGPU_NOALLOC_MAX_LOG_N elements (32 MiB per GPU, held until the process ends), so log_n above that maximum is
+ * rejected with ZKGPU_ERR_INVALID_ARG; and the twiddle tables of this mode and size must already be resident
+ * (ZKGPU_ERR_NOT_LOADED otherwise): any earlier zkgpu_ntt / zkgpu_ntt_dev call on this context with the same mode at
+ * this size (for coset_ifft) or at this or a larger size (the other three modes) leaves them behind.  All contexts on
+ * one GPU share that GPU's array: calls that overlap in time on one GPU race, so serialise them (one context's calls
+ * already are).  The array is not cleared between calls; every pass overwrites all the elements the next one reads. */
+#define ZKGPU_NOALLOC_MAX_LOG_N 20
+int zkgpu_ntt_dev_noalloc(zkgpu_ctx *ctx, const void *in_dev, size_t len_in, void *out_dev, uint32_t log_n, int mode);
+
 /* Tuning knobs of the transform, for experiments and tests: log2 of the LDS tile in elements (6..12, 0 = default)
  * and log2 of the elements each thread carries per stage (1..3, 0 = default).  Results do not depend on them. */
 int zkgpu_ntt_set_params(zkgpu_ctx *ctx, uint32_t tile_log, uint32_t elems_per_thread_log);

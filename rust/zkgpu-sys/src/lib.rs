@@ -41,6 +41,7 @@ pub const ZKGPU_IFFT: c_int = 1;
 pub const ZKGPU_COSET_FFT: c_int = 2;
 pub const ZKGPU_COSET_IFFT: c_int = 3;
 pub const ZKGPU_N_SELECTORS: usize = 15;
+pub const ZKGPU_NOALLOC_MAX_LOG_N: u32 = 20;
 
 extern "C" {
     pub fn zkgpu_init(out: *mut *mut zkgpu_ctx, device_id: c_int) -> c_int;
@@ -55,6 +56,9 @@ extern "C" {
     pub fn zkgpu_ntt(ctx: *mut zkgpu_ctx, data: *mut u64, len_in: usize, log_n: u32, mode: c_int) -> c_int;
     pub fn zkgpu_ntt_dev(ctx: *mut zkgpu_ctx, in_dev: *const c_void, len_in: usize, out_dev: *mut c_void, log_n: u32,
                          mode: c_int) -> c_int;
+    /// The same transform without any allocation inside the library (static 2^20-element scratch per GPU).
+    pub fn zkgpu_ntt_dev_noalloc(ctx: *mut zkgpu_ctx, in_dev: *const c_void, len_in: usize, out_dev: *mut c_void,
+                                 log_n: u32, mode: c_int) -> c_int;
 
     pub fn zkgpu_ntt_set_params(ctx: *mut zkgpu_ctx, tile_log: u32, elems_per_thread_log: u32) -> c_int;
 

@@ -1,0 +1,71 @@
+"""zkgpu_ntt_dev_noalloc - the transform for callers that cannot allocate - against zkgpu_ntt_dev on the same inputs,
+bit for bit, through the C ABI: two calls in a row per mode, the second on a smaller input (the static scratch array
+keeps the first call's contents), plus the argument checks."""
+import numpy as np
+import pytest
+
+import model as M
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import zkvm_amd
+    c = zkvm_amd.Context(0)
+    yield c
+    c.close()
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_noalloc_matches_allocating_entry_point(ctx, orc, mode):
+    import torch
+    name = ["fft", "ifft", "coset_fft", "coset_ifft"][mode]
+    # big first, then smaller: sizes chosen so that one, two and three passes occur (tiles hold 2^9 elements)
+    for log_n, len_in in ((20, (1 << 20) - 5), (14, 1 << 14), (18, (1 << 17) + 3), (9, 300), (4, 16)):
+        n = 1 << log_n
+        x = M.random_fr_mont(len_in, 7000 + 10 * log_n + mode)
+        xd = dev(x)
+        want = ctx.ntt(xd, log_n, mode)                      # allocating entry point; also leaves the tables resident
+        got = torch.full((n, 4), -1, dtype=torch.int64, device="cuda")
+        ctx.ntt_noalloc(xd, log_n, mode, got)
+        ctx.sync()
+        assert torch.equal(got, want), (name, log_n)
+        if log_n <= 14:
+            assert np.array_equal(got.cpu().numpy().view(np.uint64), orc.fft(name, x, n)), (name, log_n)
+    # in place
+    x = M.random_fr_mont(1 << 12, 99)
+    xd = dev(x)
+    want = ctx.ntt(xd, 12, mode)
+    ctx.ntt_noalloc(xd, 12, mode, xd)
+    ctx.sync()
+    assert torch.equal(xd, want)
+
+
+def test_noalloc_rejects_what_it_cannot_serve():
+    import torch
+    import zkvm_amd
+    c = zkvm_amd.Context(0)
+    try:
+        x = dev(M.random_fr_mont(1 << 10, 5))
+        out = torch.empty((1 << 10, 4), dtype=torch.int64, device="cuda")
+        with pytest.raises(zkvm_amd.ZkGpuError) as e:      # fresh context: no tables yet
+            c.ntt_noalloc(x, 10, 0, out)
+        assert e.value.code == -7
+        c.ntt(x, 10, 0)
+        c.ntt_noalloc(x, 10, 0, out)
+        c.ntt_noalloc(x, 8, 1, out[:256])                   # the tables of a larger size serve a smaller one
+        with pytest.raises(zkvm_amd.ZkGpuError) as e:      # coset_ifft tables are per size
+            c.ntt_noalloc(x, 10, 3, out)
+        assert e.value.code == -7
+        big = torch.empty((1 << 21, 4), dtype=torch.int64, device="cuda")
+        with pytest.raises(zkvm_amd.ZkGpuError) as e:      # beyond the static scratch
+            c.ntt_noalloc(x, 21, 0, big)
+        assert e.value.code == -1 and "2^20" in str(e.value)
+    finally:
+        c.close()

@@ -51,6 +51,7 @@ SIGNATURES = {
     "zkgpu_domain_new": (C.c_int, [C.c_uint64, C.POINTER(Domain)]),
     "zkgpu_ntt": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, C.c_int]),
     "zkgpu_ntt_dev": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_uint32, C.c_int]),
+    "zkgpu_ntt_dev_noalloc": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_uint32, C.c_int]),
     "zkgpu_srs_load": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "zkgpu_srs_load_dev": (C.c_int, [_P, _P, C.c_size_t]),
     "zkgpu_msm": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),

@@ -106,6 +106,14 @@ class Context:
         self._check(self._lib.zkgpu_ntt(self._h, buf.ctypes.data, len_in if len_in <= n else n, log_n, mode))
         return buf
 
+    def ntt_noalloc(self, data, log_n, mode, out):
+        """zkgpu_ntt_dev_noalloc: the transform on device tensors without any allocation inside the library (its
+        inter-pass buffer is a static device array, 2^20 elements at most; the tables must be resident)."""
+        n = 1 << log_n
+        assert data.is_cuda and data.is_contiguous() and out.is_cuda and out.is_contiguous() and out.numel() == 4 * n
+        self._check(self._lib.zkgpu_ntt_dev_noalloc(self._h, data.data_ptr(), data.numel() // 4, out.data_ptr(), log_n, mode))
+        return out
+
     def ntt_set_params(self, tile_log=0, elems_per_thread_log=0):
         """Tuning knobs of the transform (0 = default)."""
         self._check(self._lib.zkgpu_ntt_set_params(self._h, int(tile_log), int(elems_per_thread_log)))

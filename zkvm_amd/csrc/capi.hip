@@ -24,10 +24,34 @@ struct zkgpu_ctx {
     DevBuf stage_a, stage_b;  // staging for the host-pointer entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string last_error;
+    void *noalloc_scratch = nullptr;   // this device's copy of zkgpu_noalloc_scratch (device address)
     // Calls on one context are serialised here: the reference's Prover::prove takes &self and may be called from
     // several threads (plonk/src/compiler/prover.rs:21,210), while a context owns one stream and one set of buffers.
     std::recursive_mutex lock;
 };
+
+// ---- scratch of the allocation-free entry point (zkgpu_ntt_dev_noalloc) ---------------------------------------------
+// The buffer between the passes of a transform of up to 2^ZKGPU_NOALLOC_MAX_LOG_N elements.  Every GPU the library
+// runs on holds its own copy of this array, at its own address, until the process ends.  In host code the array's
+// name is only a handle for hipGetSymbolAddress: the device address is looked up once per device in zkgpu_init and
+// kept in g_noalloc_scratch; that pointer, never the name, is what reaches the kernels.
+static __device__ __align__(256) uint4 zkgpu_noalloc_scratch[((size_t)1 << ZKGPU_NOALLOC_MAX_LOG_N) * 2];   // 32 bytes per Fr
+static const int MAX_DEVICES = 64;
+static void *g_noalloc_scratch[MAX_DEVICES] = {nullptr};
+static std::mutex g_noalloc_lock;
+
+// With `device` current: the address of this device's copy of the scratch array.
+static void *noalloc_scratch_for(int device) {
+    ZK_REQUIRE(device >= 0 && device < MAX_DEVICES, ZKGPU_ERR_INVALID_ARG, "device id beyond the library's table");
+    std::lock_guard<std::mutex> hold(g_noalloc_lock);
+    if (!g_noalloc_scratch[device]) {
+        void *ptr = nullptr;
+        ZK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(zkgpu_noalloc_scratch)));
+        ZK_REQUIRE(ptr != nullptr, ZKGPU_ERR_HIP, "hipGetSymbolAddress returned a null scratch address");
+        g_noalloc_scratch[device] = ptr;
+    }
+    return g_noalloc_scratch[device];
+}
 
 static thread_local std::string g_init_error;
 static thread_local std::string t_error;                 // message of this thread's last failing call on t_error_ctx
@@ -107,6 +131,7 @@ int zkgpu_init(zkgpu_ctx **out, int device_id) {
         ZK_HIP(hipStreamCreate(&ctx->stream));
         ZK_HIP(hipEventCreate(&ctx->ev0));
         ZK_HIP(hipEventCreate(&ctx->ev1));
+        ctx->noalloc_scratch = noalloc_scratch_for(device_id);
         ctx->ntt.reset(new NttEngine(ctx->stream));
         ctx->msm.reset(new MsmEngine(ctx->stream));
         ctx->poly.reset(new PolyEngine(ctx->stream));
@@ -183,6 +208,16 @@ int zkgpu_ntt_dev(zkgpu_ctx *ctx, const void *in_dev, size_t len_in, void *out_d
     return guarded(ctx, [&] {
         ZK_REQUIRE(mode >= 0 && mode <= 3, ZKGPU_ERR_INVALID_ARG, "ntt: mode must be 0..3");
         ctx->ntt->transform((NttMode)mode, static_cast<const Fr *>(in_dev), len_in, static_cast<Fr *>(out_dev), log_n);
+    });
+}
+
+int zkgpu_ntt_dev_noalloc(zkgpu_ctx *ctx, const void *in_dev, size_t len_in, void *out_dev, uint32_t log_n, int mode) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(mode >= 0 && mode <= 3, ZKGPU_ERR_INVALID_ARG, "ntt: mode must be 0..3");
+        ZK_REQUIRE(log_n <= ZKGPU_NOALLOC_MAX_LOG_N, ZKGPU_ERR_INVALID_ARG,
+                   "ntt_dev_noalloc: the transform exceeds the 2^20-element scratch of the allocation-free entry point");
+        ctx->ntt->transform_no_alloc((NttMode)mode, static_cast<const Fr *>(in_dev), len_in, static_cast<Fr *>(out_dev), log_n,
+                                     static_cast<Fr *>(ctx->noalloc_scratch));
     });
 }
 

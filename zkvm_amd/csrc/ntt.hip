@@ -427,12 +427,12 @@ void NttEngine::ensure_coset_powers(uint32_t log_n) {
 }
 
 // Split the k index bits into passes of at most 10 row bits; tiles hold 2^tile_log_ elements (32 bytes each in LDS).
-std::vector<NttEngine::Pass> NttEngine::plan(uint32_t k) {
-    std::vector<Pass> passes;
+NttEngine::Plan NttEngine::plan(uint32_t k) const {
+    Plan p;
     const uint32_t TILE_LOG = tile_log_, MAX_R = TILE_LOG < 10 ? TILE_LOG : 10;
     if (k <= TILE_LOG) {
-        passes.push_back(Pass{0, k, 0});
-        return passes;
+        p.pass[p.count++] = Pass{0, k, 0};
+        return p;
     }
     uint32_t L = (k + MAX_R - 1) / MAX_R;
     uint32_t hi = k;
@@ -446,18 +446,23 @@ std::vector<NttEngine::Pass> NttEngine::plan(uint32_t k) {
             uint32_t pb = k - r;  // last pass: columns are prefixes
             if (lt > pb) lt = pb;
         }
-        passes.push_back(Pass{b0, r, lt});
+        p.pass[p.count++] = Pass{b0, r, lt};
         hi = b0;
     }
-    return passes;
+    return p;
+}
+
+bool NttEngine::tables_resident(NttMode mode, uint32_t log_n) const {
+    if (mode == NTT_COSET_IFFT) return log_n == 0 || tw_cinv_.find(log_n) != tw_cinv_.end();
+    if (log_n > table_log_) return false;
+    if (mode == NTT_COSET_FFT && gpow_log_ < (log_n > 12 ? log_n : 12)) return false;
+    return true;
 }
 
 void NttEngine::transform(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n) {
     ZK_REQUIRE(log_n < TWO_ADACITY, ZKGPU_ERR_DOMAIN_SIZE, "InvalidEvalDomainSize: log2(size) must be below 32");
     ZK_REQUIRE(in != nullptr || len_in == 0, ZKGPU_ERR_INVALID_ARG, "ntt: null input");
     ZK_REQUIRE(out != nullptr, ZKGPU_ERR_INVALID_ARG, "ntt: null output");
-    const uint64_t n = 1ull << log_n;
-    if (len_in > n) len_in = n;  // Vec::resize truncates (domain.rs:146)
     const bool inverse = (mode == NTT_IFFT || mode == NTT_COSET_IFFT);
     const Fr *tw;
     if (mode == NTT_COSET_IFFT) {
@@ -467,24 +472,43 @@ void NttEngine::transform(NttMode mode, const Fr *in, size_t len_in, Fr *out, ui
         tw = inverse ? tw_inv_.as<Fr>() : tw_fwd_.as<Fr>();
     }
     if (mode == NTT_COSET_FFT) ensure_coset_powers(log_n);
+    if (plan(log_n).count > 1) work_.reserve(((size_t)1 << log_n) * sizeof(Fr));
+    run_passes(mode, in, len_in, out, log_n, tw, work_.as<Fr>());
+}
 
-    std::vector<Pass> passes = plan(log_n);
-    const size_t bytes = n * sizeof(Fr);
-    if (passes.size() > 1) work_.reserve(bytes);
+void NttEngine::transform_no_alloc(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n, Fr *work) {
+    ZK_REQUIRE(log_n < TWO_ADACITY, ZKGPU_ERR_DOMAIN_SIZE, "InvalidEvalDomainSize: log2(size) must be below 32");
+    ZK_REQUIRE(in != nullptr || len_in == 0, ZKGPU_ERR_INVALID_ARG, "ntt: null input");
+    ZK_REQUIRE(out != nullptr && work != nullptr, ZKGPU_ERR_INVALID_ARG, "ntt: null output");
+    ZK_REQUIRE(tables_resident(mode, log_n), ZKGPU_ERR_NOT_LOADED,
+               "ntt: the twiddle tables of this mode and size are not resident; run the allocating transform once first");
+    const Fr *tw;
+    if (mode == NTT_COSET_IFFT)
+        tw = log_n ? tw_cinv_.find(log_n)->second.as<Fr>() : nullptr;
+    else
+        tw = (mode == NTT_IFFT) ? tw_inv_.as<Fr>() : tw_fwd_.as<Fr>();
+    run_passes(mode, in, len_in, out, log_n, tw, work);
+}
+
+void NttEngine::run_passes(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n, const Fr *tw, Fr *work) {
+    const uint64_t n = 1ull << log_n;
+    if (len_in > n) len_in = n;  // Vec::resize truncates (domain.rs:146)
+    const bool inverse = (mode == NTT_IFFT || mode == NTT_COSET_IFFT);
+    const Plan passes = plan(log_n);
     const Fr *src = in;
-    for (size_t i = 0; i < passes.size(); i++) {
-        const bool last = (i + 1 == passes.size());
+    for (uint32_t i = 0; i < passes.count; i++) {
+        const bool last = (i + 1 == passes.count);
         NttPassArgs a;
         a.in = src;
-        a.out = last ? out : work_.as<Fr>();
+        a.out = last ? out : work;
         a.tw = tw;
         a.gl = gpow_lo_.as<Fr>();
         a.gh = gpow_hi_.as<Fr>();
         a.len_in = (i == 0) ? (uint64_t)len_in : n;
         a.log_n = log_n;
-        a.b0 = passes[i].b0;
-        a.log_r = passes[i].log_r;
-        a.log_t = passes[i].log_t;
+        a.b0 = passes.pass[i].b0;
+        a.log_r = passes.pass[i].log_r;
+        a.log_t = passes.pass[i].log_t;
         a.last = last ? 1 : 0;
         a.coset_in = (i == 0 && mode == NTT_COSET_FFT) ? 1 : 0;
         a.inv_shift = (last && inverse) ? log_n : 0;
@@ -503,7 +527,7 @@ void NttEngine::transform(NttMode mode, const Fr *in, size_t len_in, Fr *out, ui
         }
         hipLaunchKernelGGL(ntt_pass_kernel, dim3(grid), dim3(threads), lds_bytes, stream_, a);
         ZK_HIP(hipGetLastError());
-        src = work_.as<Fr>();
+        src = work;
     }
 }
 

@@ -30,6 +30,13 @@ class NttEngine {
     // Transforms `len_in` elements at `in` (zero-padded or truncated to 2^log_n, domain.rs:146) into the
     // 2^log_n elements at `out`; both are device pointers and may alias.  Asynchronous on the engine's stream.
     void transform(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n);
+    // The same transform for callers that must not allocate: `work` (2^log_n elements of device memory, distinct from
+    // `in` and `out`) takes the place of the engine's own inter-pass buffer, and the twiddle tables of this mode and
+    // size must already be resident (any earlier transform of the same mode at this or, except for coset_ifft, a
+    // larger size leaves them behind): otherwise ZKGPU_ERR_NOT_LOADED.  Calls no allocator, device or host.
+    void transform_no_alloc(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n, Fr *work);
+    // True when transform(mode, .., log_n) would find every table it needs.
+    bool tables_resident(NttMode mode, uint32_t log_n) const;
     // w^i for i < n/2 of the 2^log_n domain (device pointer into the forward stage tables); log_n >= 1
     const Fr *roots_half(uint32_t log_n);
     // Largest transform the twiddle tables currently cover (grown on demand).
@@ -45,10 +52,15 @@ class NttEngine {
     struct Pass {
         uint32_t b0, log_r, log_t;
     };
+    struct Plan {   // at most ceil(31 / 6) passes
+        Pass pass[8];
+        uint32_t count = 0;
+    };
     void ensure_tables(uint32_t log_n);
     const Fr *coset_inv_table(uint32_t log_n);
     void ensure_coset_powers(uint32_t log_n);
-    std::vector<Pass> plan(uint32_t log_n);
+    Plan plan(uint32_t log_n) const;
+    void run_passes(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n, const Fr *tw, Fr *work);
 
     hipStream_t stream_;
     uint32_t table_log_ = 0;

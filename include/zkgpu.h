@@ -153,9 +153,18 @@ int zkgpu_g1_sum_to_affine(const uint64_t *xyz, size_t count, uint64_t out_xy[12
 /* Device phase of the MSM only (no host tail, no result): used to time the kernels. */
 int zkgpu_msm_kernels_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n);
 
-/* As zkgpu_msm_kernels_dev with HIP events on the context's stream at the phase boundaries: phase_ms = digits +
- * sort + schedule, msm_accumulate_kernel alone, oversized buckets, bucket reduction (milliseconds). */
-int zkgpu_msm_profile_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, float phase_ms[4]);
+/* As zkgpu_msm_kernels_dev with HIP events on the context's stream at the phase boundaries (milliseconds):
+ *   0 digits            de-Montgomery and signed recoding
+ *   1 range partition   above 2^15 buckets: the pairs partitioned by bucket range (0 otherwise)
+ *   2 count pass        per-slice bucket histograms
+ *   3 offsets           bucket totals, their scan, per-slice cursors
+ *   4 scatter pass      table indices written bucket by bucket
+ *   5 schedule          buckets ordered by size
+ *   6 accumulate        msm_accumulate_kernel alone
+ *   7 oversized         buckets cut into workgroup tasks
+ *   8 reduce            bucket reduction */
+#define ZKGPU_MSM_PHASES 9
+int zkgpu_msm_profile_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, float phase_ms[ZKGPU_MSM_PHASES]);
 
 /* CommitKey::commit (kzg10/key.rs:108-129): degree check, then the MSM.  `coeffs` is a host buffer of `len`
  * coefficients as held by the reference's Polynomial (leading zeros allowed; the degree is computed as
@@ -238,6 +247,9 @@ int zkgpu_prover_set_sharding(zkgpu_ctx *ctx, uint64_t shard_base, uint64_t tota
  * var_base.  t_out receives 8n coefficients of which *t_len remain after dropping leading zeros. */
 int zkgpu_quotient(zkgpu_ctx *ctx, const uint64_t *polys, const size_t lens[6], const uint64_t *challenges7,
                    uint64_t *t_out, size_t *t_len);
+/* Device time in milliseconds of the pointwise quotient kernel (the three loops of quotient_poly.rs:88-95,128-191,
+ * 218-234 fused) in the most recent zkgpu_quotient or zkgpu_prove on this context, from HIP events around its launch. */
+int zkgpu_quotient_kernel_ms(zkgpu_ctx *ctx, float *ms);
 /* Permutation::compute_permutation_vec (plonk/src/composer/permutation.rs:181-245): wires and sigma_evals hold
  * 4 x n values each (sigma_evals = the FFT of the sigma polynomials, i.e. the sigma values). */
 int zkgpu_perm_z(zkgpu_ctx *ctx, uint32_t n, const uint64_t *wires, const uint64_t *sigma_evals, const uint64_t beta[4],

@@ -42,6 +42,7 @@ pub const ZKGPU_COSET_FFT: c_int = 2;
 pub const ZKGPU_COSET_IFFT: c_int = 3;
 pub const ZKGPU_N_SELECTORS: usize = 15;
 pub const ZKGPU_NOALLOC_MAX_LOG_N: u32 = 20;
+pub const ZKGPU_MSM_PHASES: usize = 9;
 
 extern "C" {
     pub fn zkgpu_init(out: *mut *mut zkgpu_ctx, device_id: c_int) -> c_int;
@@ -102,6 +103,7 @@ extern "C" {
     pub fn zkgpu_prover_key_eval8n(ctx: *mut zkgpu_ctx, which: c_int, out: *mut u64) -> c_int;
     pub fn zkgpu_quotient(ctx: *mut zkgpu_ctx, polys: *const u64, lens: *const usize, challenges7: *const u64,
                           t_out: *mut u64, t_len: *mut usize) -> c_int;
+    pub fn zkgpu_quotient_kernel_ms(ctx: *mut zkgpu_ctx, ms: *mut f32) -> c_int;
     pub fn zkgpu_perm_z(ctx: *mut zkgpu_ctx, n: u32, wires: *const u64, sigma_evals: *const u64, beta: *const u64,
                         gamma: *const u64, z_out: *mut u64) -> c_int;
     pub fn zkgpu_poly_eval(ctx: *mut zkgpu_ctx, coeffs: *const u64, len: usize, x: *const u64, out: *mut u64) -> c_int;

@@ -70,7 +70,7 @@ def test_bench_two_rank_flow(extra):
     port = 29900 + (os.getpid() % 1000) + len(extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline"] + extra
+           "--warmup", "1", "--no-cpu-baseline", "--no-sub-records"] + extra
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -78,3 +78,53 @@ def test_bench_two_rank_flow(extra):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
     assert out["scaling"] == ("weak" if extra == ["--log-gates", "10"] else "strong")
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the script starts its two ranks itself before touching the GPU
+    and relays one line.  The prove line of a multi-GPU run carries the strong-scaling record of the range-sharded
+    commitment over all ranks and the one-proof-on-all-GPUs record, whose proof must equal the single-GPU proof."""
+    import json
+    import subprocess
+    env = dict(os.environ, ZKGPU_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--log-gates", "12",
+           "--log-points", "17"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["scaling"] == "weak"
+    ms = out["msm_scaling"]
+    assert ms["ranks_seen"] == 2 and ms["n_points"] == 1 << 17 and ms["points_per_rank"] == 1 << 16 and ms["value"] > 0
+    assert ms["scaling"] == "strong"
+    sp = out["sharded_prove"]
+    assert sp["equals_single_gpu_proof"] is True and sp["ms_per_proof"] > 0
+    assert out["roofline"]["bound"] == "valu" and 0 < out["roofline"]["frac"] < 1
+    assert "cpu_baseline" not in out          # rank 0 at N = 1 only
+
+
+def test_bench_one_gpu_line_carries_all_three_metrics():
+    """N = 1: the prove line holds the live commitment and transform records beside the proof rate, a roofline entry
+    per kernel family and the CPU baseline with the host it ran on."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ZKGPU_BENCH_REHEARSAL")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--log-gates", "14", "--log-points", "18"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert out["msm"]["value"] > 0 and out["msm"]["unit"] == "Mpts/s" and out["msm"]["ranks_seen"] == 1
+    assert out["ntt"]["value"] > 0 and out["ntt"]["unit"] == "GB/s"
+    kernels = " ".join(r["kernel"] for r in out["rooflines"])
+    for name in ("ntt_pass_kernel", "quotient_kernel", "bucket reduction"):
+        assert name in kernels
+    for r in [out["roofline"]] + out["rooflines"]:
+        assert r["avg_launch_ms"] > 0 and 0 < r["frac"] < 1.05, r
+    cb = out["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["os_cpu_count"] >= 1 and "cpu_model" in cb

@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I zkvm_amd/csrc tools/ubench.hip -o tools/ubench && tools/ubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <algorithm>
 #include <vector>
 #include "ff.cuh"
 #include "fq28.cuh"
@@ -18,12 +19,11 @@ using namespace zk;
         }                                                                              \
     } while (0)
 
-static const int ITERS = 4096;
-
-// Each kernel runs a chain of 8 independent copies of one instruction per iteration (so issue rate, not latency,
-// is measured) and reports shader cycles per wave-instruction through s_memtime.
+// Each kernel runs 8 independent copies of one instruction per iteration (so issue rate, not latency, is measured),
+// `iters` iterations, and stamps the shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) around the
+// loop: their ratio is the clock the chip held while the loop ran.
 #define RATE_KERNEL(NAME, BODY)                                                                    \
-    __global__ void NAME(uint64_t *cycles, uint32_t *sink, uint32_t seed) {                        \
+    __global__ void __launch_bounds__(256) NAME(uint64_t *cycles, uint32_t *sink, uint32_t seed, uint32_t iters) { \
         uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3;        \
         uint32_t a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;            \
         uint64_t q0 = a0, q1 = a1, q2 = a2, q3 = a3, q4 = a4, q5 = a5, q6 = a6, q7 = a7;            \
@@ -31,14 +31,17 @@ static const int ITERS = 4096;
         uint32_t m = seed | 1;                                                                      \
         double dm = 1.0000001;                                                                      \
         (void)q0; (void)d0; (void)dm; (void)m;                                                      \
-        uint64_t t0 = __builtin_amdgcn_s_memtime();                                                 \
-        for (int i = 0; i < ITERS; i++) { BODY }                                                    \
-        uint64_t t1 = __builtin_amdgcn_s_memtime();                                                 \
+        uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();          \
+        for (uint32_t i = 0; i < iters; i++) { BODY BODY BODY BODY }                                \
+        uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();          \
         uint32_t s = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                         \
         s ^= (uint32_t)(q0 ^ q1 ^ q2 ^ q3 ^ q4 ^ q5 ^ q6 ^ q7);                                     \
         s ^= (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);                                     \
         sink[blockIdx.x * blockDim.x + threadIdx.x] = s;                                            \
-        if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;                                         \
+        if (threadIdx.x == 0) {                                                                     \
+            cycles[2 * blockIdx.x] = t1 - t0;                                                       \
+            cycles[2 * blockIdx.x + 1] = r1 - r0;                                                   \
+        }                                                                                           \
     }
 
 #define X8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
@@ -91,40 +94,47 @@ __global__ void k_field_mul(F *out, uint32_t iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = F::add(a, b);
 }
 
+// Workgroups of 256 threads (one wave per SIMD of a CU), 8 per CU in the grid; `waves_per_simd` of them are resident on
+// a CU at a time (the dynamic LDS request caps the occupancy), so every SIMD holds that many waves for the whole launch
+// and the launch lasts several milliseconds.  Reports the chip-wide issue rate, the clock held, and from the two the
+// cycles one SIMD spends per wave-instruction.
+static int g_cus = 256;
 template <class K>
-static int run_rate(const char *name, K kernel, int waves_per_simd) {
-    // one block of 256*waves_per_simd threads per CU-ish; cycles reported by wave 0 of each block
-    const int blocks = 256, threads = 256 * waves_per_simd > 1024 ? 1024 : 256 * waves_per_simd;
+static int run_rate(const char *name, K kernel, int waves_per_simd, uint32_t iters) {
+    const int blocks = g_cus * 8, threads = 256;
+    const size_t lds = (size_t)(160 * 1024) / waves_per_simd - (waves_per_simd > 1 ? 512 : 0);
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     uint64_t *cyc;
     uint32_t *sink;
-    CHECK(hipMalloc(&cyc, blocks * 8));
+    CHECK(hipMalloc(&cyc, (size_t)blocks * 16));
     CHECK(hipMalloc(&sink, (size_t)blocks * threads * 4));
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, 0, cyc, sink, 12345u);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, 0, cyc, sink, 12345u, iters / 8);
     CHECK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), 0, 0, cyc, sink, 777u);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, 0, cyc, sink, 777u, iters);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<uint64_t> h(blocks);
-    CHECK(hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost));
-    double avg = 0;
-    for (auto v : h) avg += (double)v;
-    avg /= blocks;
-    const double insts_per_wave = (double)ITERS * 8;
-    const double waves_on_simd = threads / 256.0;  // 4 SIMDs per CU, one block per CU
-    // s_memtime ticks at a constant 100 MHz on this part; convert with the wall time of the launch instead
-    double total_wave_insts = insts_per_wave * blocks * (threads / 64.0);
-    double ginst = total_wave_insts / (ms * 1e-3) / 1e9;
-    printf("%-10s waves/SIMD=%d  memtime ticks/block=%.0f  launch %.3f ms  -> %.2f G wave-inst/s chip-wide, "
-           "%.3f ns per wave-inst per SIMD\n",
-           name, (int)waves_on_simd, avg, ms, ginst, (ms * 1e6) / (insts_per_wave * waves_on_simd));
+    std::vector<uint64_t> h((size_t)blocks * 2);
+    CHECK(hipMemcpy(h.data(), cyc, (size_t)blocks * 16, hipMemcpyDeviceToHost));
+    std::vector<double> clk(blocks);
+    for (int i = 0; i < blocks; i++) clk[i] = h[2 * i + 1] ? (double)h[2 * i] / (double)h[2 * i + 1] * 0.1 : 0.0;   // GHz
+    std::sort(clk.begin(), clk.end());
+    const double ghz = clk[blocks / 2];
+    const double insts_per_wave = (double)iters * 32;
+    const double total_wave_insts = insts_per_wave * blocks * (threads / 64.0);
+    const double ginst = total_wave_insts / (ms * 1e-3) / 1e9;
+    const double simds = g_cus * 4.0;
+    printf("%-10s waves/SIMD=%d  launch %8.3f ms  clock %.2f GHz  %8.1f G wave-inst/s chip-wide  %.2f cycles per wave-inst per SIMD\n",
+           name, waves_per_simd, ms, ghz, ginst, simds * ghz / ginst);
     CHECK(hipFree(cyc));
     CHECK(hipFree(sink));
+    CHECK(hipEventDestroy(e0));
+    CHECK(hipEventDestroy(e1));
     return 0;
 }
 
@@ -153,27 +163,29 @@ static int run_field(const char *name, int threads_per_block, int blocks) {
 int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
+    g_cus = prop.multiProcessorCount;
     printf("device: %s, %d CUs, clock %d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
-    for (int w = 1; w <= 4; w *= 2) {
-        if (run_rate("fma_f32", k_fma32, w)) return 1;
-        if (run_rate("add_co", k_add, w)) return 1;
-        if (run_rate("addc_co", k_addc, w)) return 1;
-        if (run_rate("add_u64", k_add64, w)) return 1;
-        if (run_rate("mad_u24", k_mad24, w)) return 1;
-        if (run_rate("mul_lo", k_mullo, w)) return 1;
-        if (run_rate("mul_hi", k_mulhi, w)) return 1;
-        if (run_rate("mad_u64", k_mad64, w)) return 1;
-        if (run_rate("lshr_b64", k_shr64, w)) return 1;
-        if (run_rate("and_b32", k_and, w)) return 1;
-        if (run_rate("alignbit", k_align, w)) return 1;
-        if (run_rate("lshr_b32", k_shr32, w)) return 1;
-        if (run_rate("add3_u32", k_add3, w)) return 1;
-        if (run_rate("fma_f64", k_fma64, w)) return 1;
+    const uint32_t iters = 16384;   // x 32 instructions per wave: several milliseconds per launch
+    for (int w = 1; w <= 8; w *= 2) {
+        if (run_rate("fma_f32", k_fma32, w, iters)) return 1;
+        if (run_rate("mad_u64", k_mad64, w, iters)) return 1;
+        if (run_rate("mul_lo", k_mullo, w, iters)) return 1;
+        if (run_rate("mul_hi", k_mulhi, w, iters)) return 1;
+        if (run_rate("add_co", k_add, w, iters)) return 1;
+        if (run_rate("addc_co", k_addc, w, iters)) return 1;
+        if (run_rate("add_u64", k_add64, w, iters)) return 1;
+        if (run_rate("mad_u24", k_mad24, w, iters)) return 1;
+        if (run_rate("lshr_b64", k_shr64, w, iters)) return 1;
+        if (run_rate("and_b32", k_and, w, iters)) return 1;
+        if (run_rate("alignbit", k_align, w, iters)) return 1;
+        if (run_rate("lshr_b32", k_shr32, w, iters)) return 1;
+        if (run_rate("add3_u32", k_add3, w, iters)) return 1;
+        if (run_rate("fma_f64", k_fma64, w, iters)) return 1;
     }
     for (int tpb : {256, 512, 1024}) {
-        if (run_field<Fr>("Fr::mul", tpb, 2048)) return 1;
-        if (run_field<Fq>("Fq::mul", tpb, 2048)) return 1;
-        if (run_field<Fq28>("Fq28::mul", tpb, 2048)) return 1;
+        if (run_field<Fr>("Fr::mul", tpb, 8192)) return 1;
+        if (run_field<Fq>("Fq::mul", tpb, 8192)) return 1;
+        if (run_field<Fq28>("Fq28::mul", tpb, 8192)) return 1;
     }
     return 0;
 }

@@ -13,6 +13,9 @@ from . import _lib
 from ._lib import ZkGpuError
 
 FFT, IFFT, COSET_FFT, COSET_IFFT = 0, 1, 2, 3
+# phases of zkgpu_msm_profile_dev, in order
+MSM_PHASE_NAMES = ("digits", "range_partition", "count_pass", "offsets", "scatter_pass", "schedule", "accumulate",
+                   "oversized", "reduce")
 
 
 class InvalidEvalDomainSize(ValueError):
@@ -188,9 +191,17 @@ class Context:
 
     def msm_profile(self, scalars_dev):
         """Phase times of one device MSM (HIP events on the library's stream), milliseconds."""
-        ms = (C.c_float * 4)()
+        ms = (C.c_float * len(MSM_PHASE_NAMES))()
         self._check(self._lib.zkgpu_msm_profile_dev(self._h, scalars_dev.data_ptr(), scalars_dev.numel() // 4, ms))
-        return dict(zip(("sort", "accumulate", "oversized", "reduce"), [float(x) for x in ms]))
+        out = dict(zip(MSM_PHASE_NAMES, [float(x) for x in ms]))
+        out["sort"] = sum(out[k] for k in MSM_PHASE_NAMES[:6])     # everything before the accumulate launch
+        return out
+
+    def quotient_kernel_ms(self):
+        """Device milliseconds of the quotient kernel in the most recent quotient / proof on this context."""
+        ms = C.c_float(0)
+        self._check(self._lib.zkgpu_quotient_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
 
     def commit(self, coeffs):
         c = _np_u64(coeffs, 4)

@@ -351,24 +351,29 @@ int zkgpu_msm_kernels_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n) {
     });
 }
 
-int zkgpu_msm_profile_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, float phase_ms[4]) {
+int zkgpu_msm_profile_dev(zkgpu_ctx *ctx, const void *scalars_dev, size_t n, float phase_ms[ZKGPU_MSM_PHASES]) {
+    static_assert(ZKGPU_MSM_PHASES == MsmEngine::N_PHASES, "phase count of the header and the engine differ");
     return guarded(ctx, [&] {
         ZK_REQUIRE(scalars_dev != nullptr && n > 0 && phase_ms, ZKGPU_ERR_INVALID_ARG, "msm_profile: null argument");
-        hipEvent_t ev[5];
-        for (auto &e : ev) ZK_HIP(hipEventCreate(&e));
-        ctx->msm->set_profile_events(ev);
-        uint32_t groups, log_seg;
-        try {
-            ctx->msm->msm_device(static_cast<const Fr *>(scalars_dev), n, 0, groups, log_seg);
-        } catch (...) {
+        hipEvent_t ev[ZKGPU_MSM_PHASES + 1];
+        for (auto &e : ev) e = nullptr;
+        auto drop = [&] {
             ctx->msm->set_profile_events(nullptr);
-            for (auto &e : ev) (void)hipEventDestroy(e);
+            for (auto &e : ev)
+                if (e) (void)hipEventDestroy(e);
+        };
+        try {
+            for (auto &e : ev) ZK_HIP(hipEventCreate(&e));
+            ctx->msm->set_profile_events(ev);
+            uint32_t groups, log_seg;
+            ctx->msm->msm_device(static_cast<const Fr *>(scalars_dev), n, 0, groups, log_seg);
+            ZK_HIP(hipEventSynchronize(ev[ZKGPU_MSM_PHASES]));
+            for (int i = 0; i < ZKGPU_MSM_PHASES; i++) ZK_HIP(hipEventElapsedTime(&phase_ms[i], ev[i], ev[i + 1]));
+        } catch (...) {
+            drop();
             throw;
         }
-        ctx->msm->set_profile_events(nullptr);
-        ZK_HIP(hipEventSynchronize(ev[4]));
-        for (int i = 0; i < 4; i++) ZK_HIP(hipEventElapsedTime(&phase_ms[i], ev[i], ev[i + 1]));
-        for (auto &e : ev) (void)hipEventDestroy(e);
+        drop();
     });
 }
 
@@ -645,6 +650,13 @@ int zkgpu_quotient(zkgpu_ctx *ctx, const uint64_t *polys, const size_t lens[6], 
         ZK_HIP(hipMemcpyAsync(t_out, ctx->stage_b.p, N8 * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));
         *t_len = (size_t)len;
+    });
+}
+
+int zkgpu_quotient_kernel_ms(zkgpu_ctx *ctx, float *ms) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(ms != nullptr, ZKGPU_ERR_INVALID_ARG, "quotient_kernel_ms: null output");
+        *ms = ctx->poly->last_quotient_ms();
     });
 }
 

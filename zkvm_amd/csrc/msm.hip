@@ -1070,7 +1070,10 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     ZK_HIP(hipMemsetAsync(task_count, 0, 4, stream_));
     ZK_HIP(hipMemsetAsync(class_cursor, 0, (size_t)m * (N_CLASSES + 1) * 4, stream_));
 
-    if (profile_) ZK_HIP(hipEventRecord(profile_[0], stream_));
+    auto mark = [&](int k) {
+        if (profile_) ZK_HIP(hipEventRecord(profile_[k], stream_));
+    };
+    mark(0);
     // per sum: digits and the count pass of its own items into its own B counters
     SumArgs sums;
     SortGeom *geom = sums.g;
@@ -1106,7 +1109,9 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     // The small kernels (digits, totals, cursors, schedule, and the one-level sort) cover all sums of the batch in
     // one launch each; the range partition and its sort run per sum.
     hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(max_len, 256), m), dim3(256), 0, stream_, sums, 0u, c, K);
+    mark(1);
     if (n_ranges == 1) {
+        mark(2);
         hipLaunchKernelGGL(msm_sort_kernel<0>, dim3(S_used, 1, m), dim3(1024), lds_bytes, stream_, sums, 0u, part_all, part_stride,
                            sorted_.as<uint32_t>());
     } else {
@@ -1127,11 +1132,14 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             hipLaunchKernelGGL(scan_add_kernel, dim3(ceil_div(n_cnt, 256)), dim3(256), 0, stream_, blockcnt, range_sums, n_cnt);
             hipLaunchKernelGGL(msm_range_kernel<1>, dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
                                blockcnt, mkey, mval);
+            if (m == 1) mark(2);   // with several sums the partitions and count passes alternate: all of it counts as partition
             // msm_range_kernel<1> advanced nothing in global memory: blockcnt still holds the start positions
             hipLaunchKernelGGL(msm_sort2_kernel<0>, dim3(geom[j].S * n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt, n_blocks,
                                geom[j], part, sorted_.as<uint32_t>());
         }
+        if (m > 1) mark(2);
     }
+    mark(3);
     hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(B, 256), m), dim3(256), 0, stream_, sums, 0u, part_all, part_stride,
                        counts_.as<uint32_t>());
     // one scan over all m * B buckets: every bucket's run in `sorted`
@@ -1142,6 +1150,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
                        offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb, big, tasks_.as<MsmTask>(), task_count, max_tasks);
     hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(B, 256), m), dim3(256), 0, stream_, sums, 0u, part_all, part_stride,
                        offsets_.as<uint32_t>());
+    mark(4);
     if (n_ranges == 1) {
         hipLaunchKernelGGL(msm_sort_kernel<1>, dim3(S_used, 1, m), dim3(1024), lds_bytes, stream_, sums, 0u, part_all, part_stride,
                            sorted_.as<uint32_t>());
@@ -1155,13 +1164,14 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
                                n_blocks, geom[j], part, sorted_.as<uint32_t>());
         }
     }
+    mark(5);
     // schedule: class histogram, scan, placement
     hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024), m), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
                        class_shift, big, class_cursor, order, 0u);
     hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(m), dim3(64), 0, stream_, class_cursor, 0u);
     hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024), m), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
                        class_shift, big, class_cursor, order, 0u);
-    if (profile_) ZK_HIP(hipEventRecord(profile_[1], stream_));
+    mark(6);
     // Up to 2^15 buckets per sum the launch is bound by the longest chain of additions on one lane, not by throughput:
     // the sums of a batch then share one launch, and two or more lanes share each bucket while the chains are worth
     // cutting (measured on 2^15-gate proofs: 8.8 ms with one lane per bucket and one launch per sum, 6.1 ms this way).
@@ -1187,13 +1197,13 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             else launch(msm_accumulate_kernel<4>);
         }
     }
-    if (profile_) ZK_HIP(hipEventRecord(profile_[2], stream_));
+    mark(7);
     const uint32_t big_grid = max_tasks < 2048 ? max_tasks : 2048;
     hipLaunchKernelGGL(msm_big_partial_kernel, dim3(big_grid), dim3(256), 0, stream_, table, sorted_.as<uint32_t>(),
                        tasks_.as<MsmTask>(), task_count, max_tasks, partials_.as<G1Xyzz>());
     hipLaunchKernelGGL(msm_big_combine_kernel, dim3(big_grid), dim3(256), 0, stream_, tasks_.as<MsmTask>(), task_count,
                        max_tasks, partials_.as<G1Xyzz>(), buckets_.as<G1Xyzz>());
-    if (profile_) ZK_HIP(hipEventRecord(profile_[3], stream_));
+    mark(8);
     // reduction of all sums together (partials_ is free again: the oversized-bucket kernels above have consumed it in
     // stream order); the segments of sum j are [j * segs_per_sum, (j + 1) * segs_per_sum)
     hipLaunchKernelGGL(msm_segment_kernel, dim3(ceil_div(n_segments, 256)), dim3(256), 0, stream_, buckets_.as<G1Xyzz>(), log_seg,
@@ -1202,7 +1212,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
                        segs_per_sum, n_bits, partials_.as<G1Xyzz>());
     hipLaunchKernelGGL(msm_group_final_kernel, dim3(groups * m), dim3(256), 0, stream_, partials_.as<G1Xyzz>(), blocks_per_group,
                        group_sums_.as<G1Proj>());
-    if (profile_) ZK_HIP(hipEventRecord(profile_[4], stream_));
+    mark(9);
     ZK_HIP(hipGetLastError());
     n_groups = groups;
     log_seg_out = log_seg;

@@ -49,7 +49,11 @@ class MsmEngine {
 
     // Five HIP events recorded on the stream at the phase boundaries of the next device phases: start, before and
     // after msm_accumulate_kernel, before the reduction, end.  nullptr switches the recording off.
-    void set_profile_events(hipEvent_t *five) { profile_ = five; }
+    // Phase boundaries of one device MSM, for timing with HIP events: event k is recorded after phase k - 1 ends.
+    //   digits | range partition | count pass | offsets (totals, scan, cursors) | scatter pass | schedule |
+    //   accumulate | oversized buckets | bucket reduction
+    static const int N_PHASES = 9;
+    void set_profile_events(hipEvent_t *events /* N_PHASES + 1 */) { profile_ = events; }
     static uint32_t choose_window(size_t n);
     size_t device_bytes() const;
     // Test hooks: window width used by the next load_points*, segment width of the bucket reduction.

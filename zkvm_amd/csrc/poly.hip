@@ -281,11 +281,26 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs q) {
 
 void PolyEngine::quotient(const QuotientArgs &args) {
     ZK_REQUIRE(args.n8 >= 8 && (args.n8 & (args.n8 - 1)) == 0, ZKGPU_ERR_INVALID_ARG, "quotient: 8n must be a power of two");
+    if (!q_ev_[0]) {
+        ZK_HIP(hipEventCreate(&q_ev_[0]));
+        ZK_HIP(hipEventCreate(&q_ev_[1]));
+    }
+    ZK_HIP(hipEventRecord(q_ev_[0], stream_));
     if (args.widgets)
         hipLaunchKernelGGL(quotient_kernel<true>, dim3(ceil_div(args.n8, 256)), dim3(256), 0, stream_, args);
     else
         hipLaunchKernelGGL(quotient_kernel<false>, dim3(ceil_div(args.n8, 256)), dim3(256), 0, stream_, args);
     ZK_HIP(hipGetLastError());
+    ZK_HIP(hipEventRecord(q_ev_[1], stream_));
+    q_recorded_ = true;
+}
+
+float PolyEngine::last_quotient_ms() {
+    ZK_REQUIRE(q_recorded_, ZKGPU_ERR_NOT_LOADED, "no quotient has been evaluated on this context yet");
+    ZK_HIP(hipEventSynchronize(q_ev_[1]));
+    float ms = 0;
+    ZK_HIP(hipEventElapsedTime(&ms, q_ev_[0], q_ev_[1]));
+    return ms;
 }
 
 // ---- evaluation at a point ----------------------------------------------------------------------------------
@@ -536,6 +551,8 @@ uint64_t PolyEngine::length_without_leading_zeros(const Fr *coeffs, uint64_t len
 }
 
 PolyEngine::~PolyEngine() {
+    for (auto &e : q_ev_)
+        if (e) (void)hipEventDestroy(e);
     s0_.release();
     s1_.release();
     s2_.release();

@@ -53,6 +53,9 @@ class PolyEngine {
                        const Fr *roots_half, uint32_t n, Fr *z_out);
     // Pointwise quotient over the 8n coset (plonk/src/proof_system/quotient_poly.rs:88-95,128-190,218-234).
     void quotient(const QuotientArgs &args);
+    // Milliseconds the most recent quotient launch took on the device (HIP events recorded around every launch);
+    // waits for that launch.  Throws ZKGPU_ERR_NOT_LOADED before the first launch.
+    float last_quotient_ms();
     // out[j] = sum_i coeffs_j[i] * x_j^i  (plonk/src/fft/polynomial.rs:105-119), results in device memory
     void evaluate(const EvalJob *jobs, int n_jobs, Fr *out_dev);
     // out[i] = sum_k scalar_k * P_k[i] (+ constant at i = 0)
@@ -80,6 +83,8 @@ class PolyEngine {
    private:
     hipStream_t stream_;
     DevBuf s0_, s1_, s2_, s3_, jobs_;
+    hipEvent_t q_ev_[2] = {nullptr, nullptr};   // around the quotient kernel, created at the first launch
+    bool q_recorded_ = false;
 };
 
 }  // namespace zk

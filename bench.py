@@ -472,6 +472,7 @@ def run_prove(args, rank, world, local, device):
         from zkvm_amd import sharding
         base, count = shard_srs(ctx, n + 7, rank, world)
         sharding.enable_prover_sharding(ctx, base, n + 7, comm_device(device))
+        sharding.enable_collectives(ctx, comm_device(device))       # 2, 4 or 8 ranks: the 8n-point work is shared too
     else:
         if args.msm_window or args.msm_segment:
             ctx.msm_set_params(args.msm_window, args.msm_segment)
@@ -558,6 +559,7 @@ def run_prove(args, rank, world, local, device):
             sctx = zkvm_amd.Context(local)
             base, count = shard_srs(sctx, n + 7, rank, world)
             sharding.enable_prover_sharding(sctx, base, n + 7, comm_device(device))
+            sharding.enable_collectives(sctx, comm_device(device))
             sel_shape = [15, n, 4]
             if rank == 0:
                 sel = np.ascontiguousarray(selectors)
@@ -582,8 +584,12 @@ def run_prove(args, rank, world, local, device):
                 assert same, "the sharded proof differs from the single-GPU proof of the same circuit"
                 out["sharded_prove"] = {"ms_per_proof": round(1e3 * s_elapsed / s_steps, 3), "steps": s_steps,
                                         "equals_single_gpu_proof": same,
-                                        "parallelism": "one proof on %d GPUs: SRS point ranges per GPU, partial sums "
-                                                       "all-gathered per commitment batch, the rest replicated" % world}
+                                        "coset_points_per_gpu": sp.key_eval8n_len(),
+                                        "parallelism": "one proof on %d GPUs: SRS point ranges per GPU with the partial sums "
+                                                       "all-gathered per commitment batch; with 2, 4 or 8 GPUs the 8n coset is "
+                                                       "dealt out cyclically (key vectors, coset transforms and quotient on 1/N "
+                                                       "of the points, inverse transform through an all-to-all transpose and an "
+                                                       "all-gather); n-point work replicated" % world}
             sctx.close()
     return value, elapsed, out, ctx
 
@@ -712,7 +718,9 @@ def main():
         if args.sharded and world > 1:
             line["scaling"] = "strong"
             line["config"]["parallelism"] = ("one proof on %d GPUs: SRS point ranges per GPU, 144-byte partial sums "
-                                             "all-gathered over RCCL per commitment batch, the rest replicated" % world)
+                                             "all-gathered over RCCL per commitment batch; the 8n coset dealt out cyclically "
+                                             "(sharded quotient, four-step inverse transform with all-to-all); n-point work "
+                                             "replicated" % world)
     elif args.workload == "ntt":
         value, elapsed, extra, ctx = run_ntt(args, rank, world, local, device)
         line = {"metric": "Fr NTT GB/s", "unit": "GB/s", "scaling": "weak", "dtype": "u32x8 (255-bit Fr, Montgomery)",

@@ -228,9 +228,12 @@ int zkgpu_prover_to_bytes(zkgpu_ctx *ctx, uint8_t *out, size_t cap, size_t *writ
 /* The 15 commitments of the loaded key (x | y, 12 limbs each) and their infinity flags. */
 int zkgpu_prover_key_commitments(zkgpu_ctx *ctx, uint64_t *out_xy, uint8_t *out_infinity);
 /* Copies of key members for inspection: coefficient vector `which` (n elements), and the 8n coset evaluations
- * `which` in 0..14 (selectors), 15 (linear_evaluations) or 16 (L_1, unscaled). */
+ * `which` in 0..14 (selectors), 15 (linear_evaluations) or 16 (L_1, unscaled); for a key loaded under
+ * zkgpu_set_collective the latter are this rank's 8n / world elements i = rank + world * k. */
 int zkgpu_prover_key_poly(zkgpu_ctx *ctx, int which, uint64_t *out);
 int zkgpu_prover_key_eval8n(zkgpu_ctx *ctx, int which, uint64_t *out);
+/* Elements zkgpu_prover_key_eval8n writes: 8n, or 8n / world for a shared key; 0 when no key is loaded. */
+size_t zkgpu_prover_key_eval_len(const zkgpu_ctx *ctx);
 
 /* Multi-GPU proving, one context per GPU: this context's SRS holds the points [shard_base, shard_base + its point
  * count) of an SRS of total_points points.  Every commitment of zkgpu_prover_key_load and zkgpu_prove then sums this
@@ -241,6 +244,42 @@ int zkgpu_prover_key_eval8n(zkgpu_ctx *ctx, int which, uint64_t *out);
 typedef int (*zkgpu_exchange_fn)(void *user, const uint64_t *mine, size_t m, uint64_t *all);
 int zkgpu_prover_set_sharding(zkgpu_ctx *ctx, uint64_t shard_base, uint64_t total_points, uint32_t world,
                               zkgpu_exchange_fn exchange, void *user);
+
+/* ---- one transform, one quotient over several GPUs ----------------------------------------------------------------
+ * No counterpart in the reference, whose best_fft (plonk/src/fft/domain.rs:286-340) and quotient loops
+ * (quotient_poly.rs:86-95,128-191,218-234) run on one host.  One context per GPU, `world` = 2, 4 or 8 of them.
+ *
+ * The 2^log_n evaluation points are dealt out cyclically: rank c owns the points k = c + world * k'.  They form the
+ * coset (g) w^c <w^world>, so a rank computes its evaluations of a polynomial it holds in full with one local
+ * transform of 2^log_n / world points and no exchange (zkgpu_ntt_slice_dev).  The way back
+ * (zkgpu_intt_sharded_dev) is a four-step transform whose small dimension lies across the GPUs: local inverse
+ * transform, all-to-all transpose (2^log_n * 32 / world^2 bytes to every peer), a world-point inverse DFT on every
+ * rank's index range, and an all-gather that leaves all coefficients on every rank.  Because world divides 8, the
+ * quotient's "next row" i + 8 (quotient_poly.rs:53-59) stays inside a rank's slice: no halo is exchanged.
+ *
+ * The exchanges go through the caller: `fn(user, op, send_dev, recv_dev, block_bytes)` runs one collective on DEVICE
+ * buffers and returns 0 once recv_dev holds the data (the library has synchronised its stream before the call and
+ * launches nothing during it):
+ *   op ZKGPU_ALL_TO_ALL   send_dev holds world blocks of block_bytes, block r for rank r; recv_dev receives block r
+ *                         from rank r
+ *   op ZKGPU_ALL_GATHER   send_dev holds one block; recv_dev receives the blocks of all ranks in rank order
+ * zkgpu_set_collective registers it (fn == NULL removes it).  A prover key loaded afterwards
+ * (zkgpu_prover_key_load) keeps only this rank's slice of every 8n-point vector (1 / world of the ProverKey's
+ * memory), and zkgpu_prove / zkgpu_quotient evaluate the quotient on that slice; all ranks must then call them
+ * together, and all obtain the same proof.  Combine with zkgpu_prover_set_sharding to share the commitments too. */
+#define ZKGPU_ALL_TO_ALL 0
+#define ZKGPU_ALL_GATHER 1
+typedef int (*zkgpu_collective_fn)(void *user, int op, const void *send_dev, void *recv_dev, size_t block_bytes);
+int zkgpu_set_collective(zkgpu_ctx *ctx, uint32_t rank, uint32_t world, zkgpu_collective_fn fn, void *user);
+/* This rank's slice of fft / coset_fft (mode ZKGPU_FFT or ZKGPU_COSET_FFT) of the len_in coefficients at in_dev over the
+ * 2^log_n domain: out_dev receives 2^log_n / world elements, out[k'] = the transform's element rank + world * k'.
+ * world is a power of two; asynchronous on the context's stream; needs no collective. */
+int zkgpu_ntt_slice_dev(zkgpu_ctx *ctx, const void *in_dev, size_t len_in, void *out_dev, uint32_t log_n, int mode,
+                        uint32_t rank, uint32_t world);
+/* ifft / coset_ifft (mode ZKGPU_IFFT or ZKGPU_COSET_IFFT) of evaluations held as slices by the ranks of
+ * zkgpu_set_collective: slice_dev holds this rank's 2^log_n / world evaluations, out_dev receives all 2^log_n
+ * coefficients on every rank.  Collective: every rank calls it.  Needs 2^log_n >= world^2. */
+int zkgpu_intt_sharded_dev(zkgpu_ctx *ctx, const void *slice_dev, void *out_dev, uint32_t log_n, int mode);
 
 /* build_quotient_polynomial (plonk/src/proof_system/quotient_poly.rs:15-100).  `polys` packs the coefficient
  * vectors z, a, b, c, d, pi back to back with lens[6]; challenges7 = alpha beta gamma range logic fixed_base

@@ -43,6 +43,8 @@ pub const ZKGPU_COSET_IFFT: c_int = 3;
 pub const ZKGPU_N_SELECTORS: usize = 15;
 pub const ZKGPU_NOALLOC_MAX_LOG_N: u32 = 20;
 pub const ZKGPU_MSM_PHASES: usize = 9;
+pub const ZKGPU_ALL_TO_ALL: c_int = 0;
+pub const ZKGPU_ALL_GATHER: c_int = 1;
 
 extern "C" {
     pub fn zkgpu_init(out: *mut *mut zkgpu_ctx, device_id: c_int) -> c_int;
@@ -93,6 +95,13 @@ extern "C" {
     pub fn zkgpu_prover_set_sharding(ctx: *mut zkgpu_ctx, shard_base: u64, total_points: u64, world: u32,
                                      exchange: Option<unsafe extern "C" fn(*mut c_void, *const u64, usize, *mut u64) -> c_int>,
                                      user: *mut c_void) -> c_int;
+    pub fn zkgpu_set_collective(ctx: *mut zkgpu_ctx, rank: u32, world: u32,
+                                fn_: Option<unsafe extern "C" fn(*mut c_void, c_int, *const c_void, *mut c_void, usize) -> c_int>,
+                                user: *mut c_void) -> c_int;
+    pub fn zkgpu_ntt_slice_dev(ctx: *mut zkgpu_ctx, in_dev: *const c_void, len_in: usize, out_dev: *mut c_void, log_n: u32,
+                               mode: c_int, rank: u32, world: u32) -> c_int;
+    pub fn zkgpu_intt_sharded_dev(ctx: *mut zkgpu_ctx, slice_dev: *const c_void, out_dev: *mut c_void, log_n: u32,
+                                  mode: c_int) -> c_int;
     pub fn zkgpu_prover_key_load(ctx: *mut zkgpu_ctx, n: u32, constraints: u64, selector_evals: *const u64,
                                  label: *const c_char, label_len: usize, pi_indexes: *const u64, n_pi: usize) -> c_int;
     pub fn zkgpu_prover_load_bytes(ctx: *mut zkgpu_ctx, bytes: *const u8, len: usize, pi_indexes: *const u64, n_pi: usize,
@@ -101,6 +110,7 @@ extern "C" {
     pub fn zkgpu_prover_key_commitments(ctx: *mut zkgpu_ctx, out_xy: *mut u64, out_infinity: *mut u8) -> c_int;
     pub fn zkgpu_prover_key_poly(ctx: *mut zkgpu_ctx, which: c_int, out: *mut u64) -> c_int;
     pub fn zkgpu_prover_key_eval8n(ctx: *mut zkgpu_ctx, which: c_int, out: *mut u64) -> c_int;
+    pub fn zkgpu_prover_key_eval_len(ctx: *const zkgpu_ctx) -> usize;
     pub fn zkgpu_quotient(ctx: *mut zkgpu_ctx, polys: *const u64, lens: *const usize, challenges7: *const u64,
                           t_out: *mut u64, t_len: *mut usize) -> c_int;
     pub fn zkgpu_quotient_kernel_ms(ctx: *mut zkgpu_ctx, ms: *mut f32) -> c_int;

@@ -74,11 +74,15 @@ SIGNATURES = {
     "zkgpu_g1_bucket_selfcheck": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P]),
     "zkgpu_g1_bucket_selfcheck_tree": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P]),
     "zkgpu_prover_set_sharding": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, _P, _P]),
+    "zkgpu_set_collective": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
+    "zkgpu_ntt_slice_dev": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32]),
+    "zkgpu_intt_sharded_dev": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_int]),
     "zkgpu_prover_key_load": (C.c_int, [_P, C.c_uint32, C.c_uint64, _P, C.c_char_p, C.c_size_t, _P, C.c_size_t]),
     "zkgpu_prover_load_bytes": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "zkgpu_prover_to_bytes": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "zkgpu_prover_key_commitments": (C.c_int, [_P, _P, _P]),
     "zkgpu_prover_key_poly": (C.c_int, [_P, C.c_int, _P]),
+    "zkgpu_prover_key_eval_len": (C.c_size_t, [_P]),
     "zkgpu_prover_key_eval8n": (C.c_int, [_P, C.c_int, _P]),
     "zkgpu_quotient": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_size_t)]),
     "zkgpu_quotient_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),

@@ -117,6 +117,29 @@ class Context:
         self._check(self._lib.zkgpu_ntt_dev_noalloc(self._h, data.data_ptr(), data.numel() // 4, out.data_ptr(), log_n, mode))
         return out
 
+    def ntt_slice(self, data, log_n, mode, rank, world, out=None):
+        """zkgpu_ntt_slice_dev: elements rank + world * k of fft / coset_fft of `data` (a CUDA tensor) over the 2^log_n
+        domain, with one local transform of 2^log_n / world points."""
+        import torch
+        m = (1 << log_n) // world
+        if out is None:
+            out = torch.empty((m, 4), dtype=torch.int64, device=data.device)
+        assert data.is_cuda and data.is_contiguous() and out.is_contiguous() and out.numel() == 4 * m
+        self._check(self._lib.zkgpu_ntt_slice_dev(self._h, data.data_ptr(), data.numel() // 4, out.data_ptr(), log_n, mode,
+                                                  rank, world))
+        return out
+
+    def intt_sharded(self, slice_dev, log_n, mode, out=None):
+        """zkgpu_intt_sharded_dev: ifft / coset_ifft of evaluations held as slices by the ranks registered with
+        sharding.enable_collectives -> all 2^log_n coefficients.  Collective: every rank calls it."""
+        import torch
+        n = 1 << log_n
+        if out is None:
+            out = torch.empty((n, 4), dtype=torch.int64, device=slice_dev.device)
+        assert slice_dev.is_cuda and slice_dev.is_contiguous() and out.is_contiguous() and out.numel() == 4 * n
+        self._check(self._lib.zkgpu_intt_sharded_dev(self._h, slice_dev.data_ptr(), out.data_ptr(), log_n, mode))
+        return out
+
     def ntt_set_params(self, tile_log=0, elems_per_thread_log=0):
         """Tuning knobs of the transform (0 = default)."""
         self._check(self._lib.zkgpu_ntt_set_params(self._h, int(tile_log), int(elems_per_thread_log)))
@@ -383,8 +406,13 @@ class Prover:
         self.ctx._check(self.ctx._lib.zkgpu_prover_key_poly(self.ctx._h, which, out.ctypes.data))
         return out
 
+    def key_eval8n_len(self):
+        """Elements of one key vector over the 8n coset held by this context: 8n, or 8n / world under
+        sharding.enable_collectives (the slice i = rank + world * k)."""
+        return int(self.ctx._lib.zkgpu_prover_key_eval_len(self.ctx._h))
+
     def key_eval8n(self, which):
-        out = np.zeros((8 * self.n, 4), dtype=np.uint64)
+        out = np.zeros((self.key_eval8n_len(), 4), dtype=np.uint64)
         self.ctx._check(self.ctx._lib.zkgpu_prover_key_eval8n(self.ctx._h, which, out.ctypes.data))
         return out
 

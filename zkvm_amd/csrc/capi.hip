@@ -24,6 +24,7 @@ struct zkgpu_ctx {
     DevBuf stage_a, stage_b;  // staging for the host-pointer entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string last_error;
+    Collective coll;                   // as set by zkgpu_set_collective
     void *noalloc_scratch = nullptr;   // this device's copy of zkgpu_noalloc_scratch (device address)
     // Calls on one context are serialised here: the reference's Prover::prove takes &self and may be called from
     // several threads (plonk/src/compiler/prover.rs:21,210), while a context owns one stream and one set of buffers.
@@ -596,6 +597,38 @@ int zkgpu_prover_set_sharding(zkgpu_ctx *ctx, uint64_t shard_base, uint64_t tota
     return guarded(ctx, [&] { ctx->prover->set_sharding(shard_base, total_points, world, exchange, user); });
 }
 
+int zkgpu_set_collective(zkgpu_ctx *ctx, uint32_t rank, uint32_t world, zkgpu_collective_fn fn, void *user) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(fn == nullptr || (world >= 1 && rank < world), ZKGPU_ERR_INVALID_ARG, "set_collective: rank outside the world");
+        ctx->coll.fn = fn;
+        ctx->coll.user = user;
+        ctx->coll.rank = fn ? rank : 0;
+        ctx->coll.world = fn ? world : 1;
+        ctx->prover->set_collective(rank, world, fn, user);
+    });
+}
+
+int zkgpu_ntt_slice_dev(zkgpu_ctx *ctx, const void *in_dev, size_t len_in, void *out_dev, uint32_t log_n, int mode,
+                        uint32_t rank, uint32_t world) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(mode == ZKGPU_FFT || mode == ZKGPU_COSET_FFT, ZKGPU_ERR_INVALID_ARG, "ntt_slice: mode must be fft or coset_fft");
+        ZK_REQUIRE(out_dev != nullptr && (in_dev != nullptr || len_in == 0), ZKGPU_ERR_INVALID_ARG, "ntt_slice: null buffer");
+        ctx->ntt->slice_forward(mode == ZKGPU_COSET_FFT, static_cast<const Fr *>(in_dev), len_in, static_cast<Fr *>(out_dev), log_n,
+                                rank, world);
+    });
+}
+
+int zkgpu_intt_sharded_dev(zkgpu_ctx *ctx, const void *slice_dev, void *out_dev, uint32_t log_n, int mode) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(mode == ZKGPU_IFFT || mode == ZKGPU_COSET_IFFT, ZKGPU_ERR_INVALID_ARG, "intt_sharded: mode must be ifft or coset_ifft");
+        ZK_REQUIRE(slice_dev != nullptr && out_dev != nullptr, ZKGPU_ERR_INVALID_ARG, "intt_sharded: null buffer");
+        ZK_REQUIRE(log_n < 32, ZKGPU_ERR_DOMAIN_SIZE, "InvalidEvalDomainSize: log2(size) must be below 32");
+        ZK_REQUIRE(ctx->coll.fn != nullptr, ZKGPU_ERR_NOT_LOADED, "intt_sharded: call zkgpu_set_collective first");
+        ctx->ntt->inverse_sharded(mode == ZKGPU_COSET_IFFT, static_cast<const Fr *>(slice_dev), static_cast<Fr *>(out_dev), log_n,
+                                  ctx->coll);
+    });
+}
+
 int zkgpu_prover_key_commitments(zkgpu_ctx *ctx, uint64_t *out_xy, uint8_t *out_infinity) {
     return guarded(ctx, [&] {
         ZK_REQUIRE(ctx->prover->loaded(), ZKGPU_ERR_NOT_LOADED, "no prover key loaded");
@@ -614,12 +647,14 @@ int zkgpu_prover_key_poly(zkgpu_ctx *ctx, int which, uint64_t *out) {
     });
 }
 
+size_t zkgpu_prover_key_eval_len(const zkgpu_ctx *ctx) { return ctx && ctx->prover->loaded() ? ctx->prover->eval_len() : 0; }
+
 int zkgpu_prover_key_eval8n(zkgpu_ctx *ctx, int which, uint64_t *out) {
     return guarded(ctx, [&] {
         ZK_REQUIRE(ctx->prover->loaded(), ZKGPU_ERR_NOT_LOADED, "no prover key loaded");
         ZK_REQUIRE(which >= 0 && which < N_SEL + 2 && out, ZKGPU_ERR_INVALID_ARG, "prover_key_eval8n: bad argument");
-        ZK_HIP(hipMemcpyAsync(out, ctx->prover->key_eval8n(which), (size_t)8 * ctx->prover->n() * sizeof(Fr),
-                              hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipMemcpyAsync(out, ctx->prover->key_eval8n(which), ctx->prover->eval_len() * sizeof(Fr), hipMemcpyDeviceToHost,
+                              ctx->stream));
         ZK_HIP(hipStreamSynchronize(ctx->stream));
     });
 }

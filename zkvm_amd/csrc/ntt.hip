@@ -339,17 +339,31 @@ NttEngine::~NttEngine() {
     tw_fwd_.release();
     tw_plain_.release();
     tw_inv_.release();
-    for (auto &kv : tw_cinv_) kv.second.release();
-    gpow_lo_.release();
-    gpow_hi_.release();
+    g_.release();
+    alt_.release();
+    fold_.release();
+    xchg_a_.release();
+    xchg_b_.release();
     work_.release();
     stage_consts_.release();
 }
 
-size_t NttEngine::device_bytes() const {
-    size_t b = tw_fwd_.cap + tw_inv_.cap + gpow_lo_.cap + gpow_hi_.cap + work_.cap + stage_consts_.cap;
-    for (auto &kv : tw_cinv_) b += kv.second.cap;
+void NttEngine::ShiftTables::release() {
+    lo.release();
+    hi.release();
+    for (auto &kv : cinv) kv.second.release();
+    cinv.clear();
+    pow_log = 0;
+}
+size_t NttEngine::ShiftTables::bytes() const {
+    size_t b = lo.cap + hi.cap;
+    for (auto &kv : cinv) b += kv.second.cap;
     return b;
+}
+
+size_t NttEngine::device_bytes() const {
+    return tw_fwd_.cap + tw_inv_.cap + tw_plain_.cap + g_.bytes() + alt_.bytes() + fold_.cap + xchg_a_.cap + xchg_b_.cap +
+           work_.cap + stage_consts_.cap;
 }
 
 static void fill_stage_tables(hipStream_t stream, DevBuf &consts_buf, Fr *table, uint32_t log_n, const Fr &w_n,
@@ -401,29 +415,37 @@ const Fr *NttEngine::roots_half(uint32_t log_n) {
     return tw_plain_.as<Fr>() + ((size_t)1 << (log_n - 1)) - 1;
 }
 
-const Fr *NttEngine::coset_inv_table(uint32_t log_n) {
-    auto it = tw_cinv_.find(log_n);
-    if (it != tw_cinv_.end()) return it->second.as<Fr>();
+const Fr *NttEngine::coset_inv_table(ShiftTables &st, uint32_t log_n) {
+    auto it = st.cinv.find(log_n);
+    if (it != st.cinv.end()) return it->second.as<Fr>();
     Domain d = Domain::make(1ull << log_n);
-    DevBuf &buf = tw_cinv_[log_n];
+    DevBuf &buf = st.cinv[log_n];
     buf.reserve((1ull << log_n) * sizeof(Fr));
-    // c_q = (g^-1)^(n/2h): for the top stage (h = n/2) that is g^-1 itself
-    fill_stage_tables(stream_, stage_consts_, buf.as<Fr>(), log_n, d.group_gen_inv, &d.generator_inv, true);
+    // c_q = (s^-1)^(n/2h): for the top stage (h = n/2) that is s^-1 itself
+    fill_stage_tables(stream_, stage_consts_, buf.as<Fr>(), log_n, d.group_gen_inv, &st.shift_inv, true);
     return buf.as<Fr>();
 }
 
-void NttEngine::ensure_coset_powers(uint32_t log_n) {
+void NttEngine::ensure_coset_powers(ShiftTables &st, uint32_t log_n) {
     uint32_t need = log_n > 12 ? log_n : 12;
-    if (gpow_log_ >= need) return;
-    Fr g = coset_generator();
-    gpow_lo_.reserve(4096 * sizeof(Fr));
+    if (st.pow_log >= need) return;
+    st.lo.reserve(4096 * sizeof(Fr));
     uint32_t n_hi = 1u << (need - 12);
-    gpow_hi_.reserve((size_t)n_hi * sizeof(Fr));
-    hipLaunchKernelGGL(gen_powers_kernel, dim3(16), dim3(256), 0, stream_, gpow_lo_.as<Fr>(), 4096u, g);
-    Fr g4096 = Fr::pow_u64(g, 4096);
-    hipLaunchKernelGGL(gen_powers_kernel, dim3(ceil_div(n_hi, 256)), dim3(256), 0, stream_, gpow_hi_.as<Fr>(), n_hi, g4096);
+    st.hi.reserve((size_t)n_hi * sizeof(Fr));
+    hipLaunchKernelGGL(gen_powers_kernel, dim3(16), dim3(256), 0, stream_, st.lo.as<Fr>(), 4096u, st.shift);
+    Fr s4096 = Fr::pow_u64(st.shift, 4096);
+    hipLaunchKernelGGL(gen_powers_kernel, dim3(ceil_div(n_hi, 256)), dim3(256), 0, stream_, st.hi.as<Fr>(), n_hi, s4096);
     ZK_HIP(hipGetLastError());
-    gpow_log_ = need;
+    st.pow_log = need;
+}
+
+void NttEngine::set_alt_shift(const Fr &s) {
+    if (alt_set_ && alt_.shift == s) return;
+    ZK_HIP(hipStreamSynchronize(stream_));   // kernels in flight may still read the old tables
+    alt_.release();
+    alt_.shift = s;
+    alt_.shift_inv = Fr::inv(s);
+    alt_set_ = true;
 }
 
 // Split the k index bits into passes of at most 10 row bits; tiles hold 2^tile_log_ elements (32 bytes each in LDS).
@@ -453,27 +475,36 @@ NttEngine::Plan NttEngine::plan(uint32_t k) const {
 }
 
 bool NttEngine::tables_resident(NttMode mode, uint32_t log_n) const {
-    if (mode == NTT_COSET_IFFT) return log_n == 0 || tw_cinv_.find(log_n) != tw_cinv_.end();
+    if (mode == NTT_COSET_IFFT) return log_n == 0 || g_.cinv.find(log_n) != g_.cinv.end();
     if (log_n > table_log_) return false;
-    if (mode == NTT_COSET_FFT && gpow_log_ < (log_n > 12 ? log_n : 12)) return false;
+    if (mode == NTT_COSET_FFT && g_.pow_log < (log_n > 12 ? log_n : 12)) return false;
     return true;
 }
 
 void NttEngine::transform(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n) {
+    if (!g_set_) {
+        g_.shift = coset_generator();
+        g_.shift_inv = Fr::inv(g_.shift);
+        g_set_ = true;
+    }
+    transform_with(g_, mode, in, len_in, out, log_n);
+}
+
+void NttEngine::transform_with(ShiftTables &st, NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n) {
     ZK_REQUIRE(log_n < TWO_ADACITY, ZKGPU_ERR_DOMAIN_SIZE, "InvalidEvalDomainSize: log2(size) must be below 32");
     ZK_REQUIRE(in != nullptr || len_in == 0, ZKGPU_ERR_INVALID_ARG, "ntt: null input");
     ZK_REQUIRE(out != nullptr, ZKGPU_ERR_INVALID_ARG, "ntt: null output");
     const bool inverse = (mode == NTT_IFFT || mode == NTT_COSET_IFFT);
     const Fr *tw;
     if (mode == NTT_COSET_IFFT) {
-        tw = log_n ? coset_inv_table(log_n) : nullptr;
+        tw = log_n ? coset_inv_table(st, log_n) : nullptr;
     } else {
         ensure_tables(log_n);
         tw = inverse ? tw_inv_.as<Fr>() : tw_fwd_.as<Fr>();
     }
-    if (mode == NTT_COSET_FFT) ensure_coset_powers(log_n);
+    if (mode == NTT_COSET_FFT) ensure_coset_powers(st, log_n);
     if (plan(log_n).count > 1) work_.reserve(((size_t)1 << log_n) * sizeof(Fr));
-    run_passes(mode, in, len_in, out, log_n, tw, work_.as<Fr>());
+    run_passes(mode, in, len_in, out, log_n, tw, work_.as<Fr>(), st);
 }
 
 void NttEngine::transform_no_alloc(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n, Fr *work) {
@@ -484,13 +515,14 @@ void NttEngine::transform_no_alloc(NttMode mode, const Fr *in, size_t len_in, Fr
                "ntt: the twiddle tables of this mode and size are not resident; run the allocating transform once first");
     const Fr *tw;
     if (mode == NTT_COSET_IFFT)
-        tw = log_n ? tw_cinv_.find(log_n)->second.as<Fr>() : nullptr;
+        tw = log_n ? g_.cinv.find(log_n)->second.as<Fr>() : nullptr;
     else
         tw = (mode == NTT_IFFT) ? tw_inv_.as<Fr>() : tw_fwd_.as<Fr>();
-    run_passes(mode, in, len_in, out, log_n, tw, work);
+    run_passes(mode, in, len_in, out, log_n, tw, work, g_);
 }
 
-void NttEngine::run_passes(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n, const Fr *tw, Fr *work) {
+void NttEngine::run_passes(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n, const Fr *tw, Fr *work,
+                           const ShiftTables &st) {
     const uint64_t n = 1ull << log_n;
     if (len_in > n) len_in = n;  // Vec::resize truncates (domain.rs:146)
     const bool inverse = (mode == NTT_IFFT || mode == NTT_COSET_IFFT);
@@ -502,8 +534,8 @@ void NttEngine::run_passes(NttMode mode, const Fr *in, size_t len_in, Fr *out, u
         a.in = src;
         a.out = last ? out : work;
         a.tw = tw;
-        a.gl = gpow_lo_.as<Fr>();
-        a.gh = gpow_hi_.as<Fr>();
+        a.gl = st.lo.as<Fr>();
+        a.gh = st.hi.as<Fr>();
         a.len_in = (i == 0) ? (uint64_t)len_in : n;
         a.log_n = log_n;
         a.b0 = passes.pass[i].b0;
@@ -529,6 +561,122 @@ void NttEngine::run_passes(NttMode mode, const Fr *in, size_t len_in, Fr *out, u
         ZK_HIP(hipGetLastError());
         src = work;
     }
+}
+
+// ---- one transform over several GPUs --------------------------------------------------------------------------------
+// out[m] = sum_q in[m + q M] * sM^q for m < min(len, M): the input modulo X^M - s^M
+__global__ void __launch_bounds__(256) ntt_fold_kernel(const Fr *in, uint64_t len, Fr *out, uint64_t M, Fr sM) {
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M || m >= len) return;
+    Fr acc = gload(in + m), pw = sM;
+    for (uint64_t j = m + M; j < len; j += M) {
+        acc = acc + gload(in + j) * pw;
+        pw = pw * sM;
+    }
+    gstore(out + m, acc);
+}
+
+// The world-point inverse DFT across the ranks' residues: recv holds block c (from rank c) at recv + c B, B elements
+// each: the coefficients of this rank's index range modulo X^M - s_c^M.  out[q B + m'] = sum_c mat[q world + c] * recv[c B + m'].
+struct CombineArgs {
+    const Fr *recv;
+    Fr *out;
+    const Fr *mat;   // world x world constants
+    uint64_t B;
+    uint32_t world;
+};
+__global__ void __launch_bounds__(256) ntt_combine_kernel(CombineArgs a) {
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.B) return;
+    Fr u[8];
+    for (uint32_t c = 0; c < a.world; c++) u[c] = gload(a.recv + c * a.B + m);
+    for (uint32_t q = 0; q < a.world; q++) {
+        Fr acc = u[0] * gload(a.mat + q * a.world);
+        for (uint32_t c = 1; c < a.world; c++) acc = acc + u[c] * gload(a.mat + q * a.world + c);
+        gstore(a.out + q * a.B + m, acc);
+    }
+}
+// gathered[r][q][m'] -> full[q M + r B + m']
+__global__ void __launch_bounds__(256) ntt_unshuffle_kernel(const Fr *gathered, Fr *full, uint64_t B, uint32_t log_world) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index into gathered
+    const uint64_t M = B << log_world;
+    if (i >= (M << log_world)) return;
+    const uint64_t r = i / M, rest = i - r * M, q = rest / B, m = rest - q * B;
+    gstore(full + q * M + r * B + m, gload(gathered + i));
+}
+
+void NttEngine::slice_forward(bool coset, const Fr *in, size_t len_in, Fr *out, uint32_t log_n, uint32_t rank, uint32_t world) {
+    ZK_REQUIRE(log_n < TWO_ADACITY, ZKGPU_ERR_DOMAIN_SIZE, "InvalidEvalDomainSize: log2(size) must be below 32");
+    uint32_t lw = 0;
+    while ((1u << lw) < world) lw++;
+    ZK_REQUIRE((1u << lw) == world && lw <= log_n && rank < world, ZKGPU_ERR_INVALID_ARG,
+               "ntt slice: the number of ranks must be a power of two not above the domain size");
+    const uint64_t n = 1ull << log_n, M = n >> lw;
+    if (len_in > n) len_in = n;   // Vec::resize truncates (domain.rs:146)
+    // this rank's points: (g) w^rank * <w^world>
+    const Domain d = Domain::make(n);
+    Fr s = Fr::pow_u64(d.group_gen, rank);
+    if (coset) s = s * coset_generator();
+    set_alt_shift(s);
+    const Fr *src = in;
+    if (len_in > M) {
+        fold_.reserve(M * sizeof(Fr));
+        hipLaunchKernelGGL(ntt_fold_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, stream_, in, (uint64_t)len_in, fold_.as<Fr>(), M,
+                           Fr::pow_u64(s, M));
+        ZK_HIP(hipGetLastError());
+        src = fold_.as<Fr>();
+        len_in = M;
+    }
+    transform_with(alt_, NTT_COSET_FFT, src, len_in, out, log_n - lw);
+}
+
+void NttEngine::inverse_sharded(bool coset, const Fr *slice, Fr *out_full, uint32_t log_n, const Collective &coll) {
+    ZK_REQUIRE(coll.fn != nullptr, ZKGPU_ERR_INVALID_ARG, "sharded inverse transform: no collective function set");
+    const uint32_t world = coll.world, lw = coll.log_world();
+    ZK_REQUIRE((1u << lw) == world && world <= 8 && 2 * lw <= log_n && coll.rank < world, ZKGPU_ERR_INVALID_ARG,
+               "sharded inverse transform: 2, 4 or 8 ranks and at least world^2 points");
+    const uint64_t n = 1ull << log_n, M = n >> lw, B = M >> lw;
+    const Domain d = Domain::make(n);
+    const Fr g = coset ? coset_generator() : Fr::one();
+    set_alt_shift(Fr::pow_u64(d.group_gen, coll.rank) * g);
+    xchg_a_.reserve(n * sizeof(Fr) + (size_t)world * world * sizeof(Fr));
+    xchg_b_.reserve(M * sizeof(Fr));
+    Fr *a = xchg_a_.as<Fr>(), *b = xchg_b_.as<Fr>();
+    Fr *mat_dev = a + n;
+    // u = the polynomial modulo X^M - s^M, natural order: block r of B elements goes to rank r
+    transform_with(alt_, NTT_COSET_IFFT, slice, M, b, log_n - lw);
+    // mat[q][c] = g^(-q M) * world^-1 * w_world^(-c q)
+    std::vector<Fr> mat((size_t)world * world);
+    {
+        const Fr w_inv = Fr::pow_u64(d.group_gen_inv, M);   // w_world^-1
+        const Fr gM_inv = Fr::inv(Fr::pow_u64(g, M));
+        const Fr world_inv = Fr::inv(Fr::from_u32(world));
+        Fr gq = world_inv;
+        for (uint32_t q = 0; q < world; q++) {
+            const Fr wq = Fr::pow_u64(w_inv, q);
+            Fr cur = gq;
+            for (uint32_t c = 0; c < world; c++) {
+                mat[(size_t)q * world + c] = cur;
+                cur = cur * wq;
+            }
+            gq = gq * gM_inv;
+        }
+    }
+    ZK_HIP(hipMemcpyAsync(mat_dev, mat.data(), mat.size() * sizeof(Fr), hipMemcpyHostToDevice, stream_));
+    ZK_HIP(hipStreamSynchronize(stream_));
+    ZK_REQUIRE(coll.fn(coll.user, 0, b, a, (size_t)B * sizeof(Fr)) == 0, ZKGPU_ERR_INTERNAL, "the all-to-all exchange failed");
+    CombineArgs ca;
+    ca.recv = a;
+    ca.out = b;
+    ca.mat = mat_dev;
+    ca.B = B;
+    ca.world = world;
+    hipLaunchKernelGGL(ntt_combine_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, stream_, ca);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(stream_));
+    ZK_REQUIRE(coll.fn(coll.user, 1, b, a, (size_t)M * sizeof(Fr)) == 0, ZKGPU_ERR_INTERNAL, "the all-gather exchange failed");
+    hipLaunchKernelGGL(ntt_unshuffle_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, a, out_full, B, lw);
+    ZK_HIP(hipGetLastError());
 }
 
 }  // namespace zk

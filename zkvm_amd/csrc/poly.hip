@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs q) {
     typedef OutlinedMul M;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= q.n8) return;
-    const uint32_t iw = (i + 8) & (q.n8 - 1);  // "next row" on the 8n coset (quotient_poly.rs:53-59,134-136)
+    const uint32_t iw = (i + q.rot) & (q.n8 - 1);  // "next row" on the 8n coset (quotient_poly.rs:53-59,134-136)
     const Fr a = ld(q.a + i), b = ld(q.b + i), c = ld(q.c + i), d = ld(q.d + i);
 
     // arithmetic/proverkey.rs:43-73
@@ -276,11 +276,13 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs q) {
     p = Fr::add(p, FM(FM(Fr::sub(z, Fr::one()), ld(q.l1 + i)), q.alpha_sq));
 
     // quotient_poly.rs:88-95: numerator / Z_H ; Z_H takes 8 values on the 8n coset
-    st(q.out + i, FM(Fr::add(t, p), q.vh_inv[i & 7]));
+    st(q.out + i, FM(Fr::add(t, p), q.vh_inv[(q.first + q.world * i) & 7]));
 }
 
 void PolyEngine::quotient(const QuotientArgs &args) {
-    ZK_REQUIRE(args.n8 >= 8 && (args.n8 & (args.n8 - 1)) == 0, ZKGPU_ERR_INVALID_ARG, "quotient: 8n must be a power of two");
+    ZK_REQUIRE(args.n8 >= args.rot && (args.n8 & (args.n8 - 1)) == 0, ZKGPU_ERR_INVALID_ARG, "quotient: 8n must be a power of two");
+    ZK_REQUIRE(args.world >= 1 && args.world * args.rot == 8 && args.first < args.world, ZKGPU_ERR_INVALID_ARG,
+               "quotient: the GPUs sharing the coset must number 1, 2, 4 or 8");
     if (!q_ev_[0]) {
         ZK_HIP(hipEventCreate(&q_ev_[0]));
         ZK_HIP(hipEventCreate(&q_ev_[1]));

@@ -89,7 +89,22 @@ size_t Prover::device_bytes() const {
     return polys_.cap + evals_.cap + sigma_.cap + work_.cap + small_.cap + pi_lagrange_.cap;
 }
 
-const Fr *Prover::key_eval8n(int k) const { return reinterpret_cast<const Fr *>(evals_.p) + (size_t)k * 8 * n_; }
+const Fr *Prover::key_eval8n(int k) const { return reinterpret_cast<const Fr *>(evals_.p) + (size_t)k * ev_len_; }
+
+void Prover::set_collective(uint32_t rank, uint32_t world, Collective::Fn fn, void *user) {
+    ZK_REQUIRE(fn == nullptr || (world >= 1 && rank < world), ZKGPU_ERR_INVALID_ARG, "set_collective: rank outside the world");
+    coll_.fn = fn;
+    coll_.user = user;
+    coll_.rank = fn ? rank : 0;
+    coll_.world = fn ? world : 1;
+}
+
+void Prover::coset_fft_8n(const Fr *coeffs, uint64_t len, Fr *out) {
+    if (shared())
+        ntt_.slice_forward(true, coeffs, len, out, log_n_ + 3, key_rank_, key_world_);
+    else
+        ntt_.transform(NTT_COSET_FFT, coeffs, len, out, log_n_ + 3);
+}
 
 int Prover::commit_dev(const Fr *coeffs, uint64_t len, AffineOut &out) { return commit_many(1, &coeffs, &len, &out); }
 
@@ -177,13 +192,13 @@ void Prover::build_l1_and_vanishing(bool with_linear) {
         two[1] = Fr::one();
         ZK_HIP(hipMemcpyAsync(tmp, two.data(), 2 * sizeof(Fr), hipMemcpyHostToDevice, stream_));
         ZK_HIP(hipStreamSynchronize(stream_));
-        ntt_.transform(NTT_COSET_FFT, tmp, 2, evals + (size_t)N_SEL * N8, log_n + 3);
+        coset_fft_8n(tmp, 2, evals + (size_t)N_SEL * ev_len_);
     }
     Fr one = Fr::one();
     ZK_HIP(hipMemcpyAsync(tmp, &one, sizeof(Fr), hipMemcpyHostToDevice, stream_));
     ZK_HIP(hipStreamSynchronize(stream_));
     ntt_.transform(NTT_IFFT, tmp, 1, tmp, log_n);
-    ntt_.transform(NTT_COSET_FFT, tmp, n, evals + (size_t)(N_SEL + 1) * N8, log_n + 3);
+    coset_fft_8n(tmp, n, evals + (size_t)(N_SEL + 1) * ev_len_);
     Domain d8 = Domain::make(N8);
     Fr g = Fr::inv(d8.generator_inv);
     Fr gn = Fr::pow_u64(g, n);
@@ -207,7 +222,7 @@ void Prover::build_pi_lagrange() {
         if (i < n_) idx.push_back(i);
     std::sort(idx.begin(), idx.end());
     idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
-    const size_t N8 = (size_t)8 * n_;
+    const size_t N8 = ev_len_;
     if (idx.empty() || idx.size() > 4 || idx.size() * N8 * sizeof(Fr) > (8ull << 30)) return;
     pi_lagrange_.reserve(idx.size() * N8 * sizeof(Fr));
     Fr *tmp = work_.as<Fr>();
@@ -215,7 +230,7 @@ void Prover::build_pi_lagrange() {
     for (size_t j = 0; j < idx.size(); j++) {
         poly_.zero_and_scatter(tmp, n_, &idx[j], &one, 1);
         ntt_.transform(NTT_IFFT, tmp, n_, tmp, log_n_);
-        ntt_.transform(NTT_COSET_FFT, tmp, n_, pi_lagrange_.as<Fr>() + j * N8, log_n_ + 3);
+        coset_fft_8n(tmp, n_, pi_lagrange_.as<Fr>() + j * N8);
     }
     ZK_HIP(hipStreamSynchronize(stream_));
     pi_lagrange_idx_ = idx;
@@ -231,8 +246,17 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
     uint32_t log_n = 0;
     while ((1u << log_n) < n) log_n++;
     const size_t N8 = (size_t)8 * n;
+    // the 8n-point work is shared when a collective is set for 2, 4 or 8 ranks and every rank's share of the
+    // inverse transform's transpose is at least one element
+    key_world_ = 1;
+    key_rank_ = 0;
+    if (coll_.usable() && N8 >= (size_t)coll_.world * coll_.world) {
+        key_world_ = coll_.world;
+        key_rank_ = coll_.rank;
+    }
+    ev_len_ = N8 / key_world_;
     polys_.reserve((size_t)N_SEL * n * sizeof(Fr));
-    evals_.reserve((size_t)(N_SEL + 2) * N8 * sizeof(Fr));
+    evals_.reserve((size_t)(N_SEL + 2) * ev_len_ * sizeof(Fr));
     sigma_.reserve((size_t)4 * n * sizeof(Fr));
     work_.reserve((size_t)N_SEL * n * sizeof(Fr));
     Fr *stage = work_.as<Fr>();
@@ -252,7 +276,7 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
         ntt_.transform(NTT_IFFT, stage + (size_t)k * n, n, polys + (size_t)k * n, log_n);
         poly_len_[k] = poly_.length_without_leading_zeros(polys + (size_t)k * n, n);
         // compiler.rs:241-301: coset_fft over the 8n domain
-        ntt_.transform(NTT_COSET_FFT, polys + (size_t)k * n, poly_len_[k], evals + (size_t)k * N8, log_n + 3);
+        coset_fft_8n(polys + (size_t)k * n, poly_len_[k], evals + (size_t)k * ev_len_);
     }
     if (poly_len_[Q_RANGE]) widgets_ |= 1u;
     if (poly_len_[Q_LOGIC]) widgets_ |= 2u;
@@ -367,6 +391,8 @@ static bool g1_decompress(const uint8_t in[48], AffineOut &out) {
 
 void Prover::load_key_bytes(const uint8_t *b, size_t len, const uint64_t *pi_indexes, size_t n_pi) {
     ZK_REQUIRE(b != nullptr && len >= 48, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: NotEnoughBytes (48-byte header)");
+    ZK_REQUIRE(!coll_.usable(), ZKGPU_ERR_INVALID_ARG,
+               "prover_load_bytes: a serialized key holds whole coset vectors; load it on a context without set_collective");
     const uint64_t label_len = rd_be64(b), pk_len = rd_be64(b + 8), ck_len = rd_be64(b + 16), vk_len = rd_be64(b + 24),
                    size = rd_be64(b + 32), constraints = rd_be64(b + 40);
     const uint64_t rest = len - 48;
@@ -416,6 +442,9 @@ void Prover::load_key_bytes(const uint8_t *b, size_t len, const uint64_t *pi_ind
 
     // CommitKey::from_slice_unchecked (kzg10/key.rs:54-66)
     n_ = 0;
+    key_world_ = 1;
+    key_rank_ = 0;
+    ev_len_ = N8;
     msm_.load_points_raw(ck, ck_len);
     ZK_REQUIRE(msm_.n_points() > 0, ZKGPU_ERR_INVALID_ARG, "prover_load_bytes: empty commit key");
 
@@ -473,6 +502,8 @@ void Prover::load_key_bytes(const uint8_t *b, size_t len, const uint64_t *pi_ind
 
 size_t Prover::to_bytes(uint8_t *out, size_t cap) {
     ZK_REQUIRE(n_ != 0, ZKGPU_ERR_NOT_LOADED, "prover_to_bytes: no key loaded");
+    ZK_REQUIRE(!shared(), ZKGPU_ERR_INVALID_ARG,
+               "prover_to_bytes: this context holds a slice of every coset vector; serialize from an unshared context");
     const uint32_t n = n_;
     const size_t N8 = (size_t)8 * n;
     const size_t eval_size = DOMAIN_BYTES + N8 * 32;
@@ -586,40 +617,42 @@ void Prover::blind_poly(const Fr *evals_dev, int hiding_degree, const Fr *blinde
 uint64_t Prover::quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4], const uint64_t wire_len[4], const Fr *pi,
                           uint64_t pi_len, const Fr ch[7], Fr *t_out, const Fr *pi_values) {
     ZK_REQUIRE(loaded(), ZKGPU_ERR_NOT_LOADED, "quotient: no prover key loaded");
-    const size_t N8 = (size_t)8 * n_;
-    small_.reserve(6 * N8 * sizeof(Fr));
+    const size_t N8 = (size_t)8 * n_, L = ev_len_;   // L = the coset points this context evaluates
+    ZK_REQUIRE(!shared() || (coll_.usable() && coll_.world == key_world_ && coll_.rank == key_rank_), ZKGPU_ERR_INVALID_ARG,
+               "quotient: the key was loaded for another set of ranks than set_collective names now");
+    small_.reserve((6 + (shared() ? 1 : 0)) * L * sizeof(Fr));
     Fr *ev = small_.as<Fr>();
     const uint32_t lg8 = log_n_ + 3;
     // quotient_poly.rs:46-51,120
-    ntt_.transform(NTT_COSET_FFT, z, z_len, ev, lg8);
-    for (int k = 0; k < 4; k++) ntt_.transform(NTT_COSET_FFT, wires[k], wire_len[k], ev + (size_t)(k + 1) * N8, lg8);
+    coset_fft_8n(z, z_len, ev);
+    for (int k = 0; k < 4; k++) coset_fft_8n(wires[k], wire_len[k], ev + (size_t)(k + 1) * L);
     if (pi != nullptr) {
-        ntt_.transform(NTT_COSET_FFT, pi, pi_len, ev + 5 * N8, lg8);
+        coset_fft_8n(pi, pi_len, ev + 5 * L);
     } else {
         ZK_REQUIRE(pi_values != nullptr && !pi_lagrange_idx_.empty(), ZKGPU_ERR_INTERNAL, "quotient: no public-input vectors");
-        LinArgs L;
-        L.n_terms = (int)pi_lagrange_idx_.size();
-        for (int j = 0; j < L.n_terms; j++) {
-            L.t[j].coeffs = pi_lagrange_.as<Fr>() + (size_t)j * N8;
-            L.t[j].len = N8;
-            L.t[j].scalar = pi_values[j];
+        LinArgs lin;
+        lin.n_terms = (int)pi_lagrange_idx_.size();
+        for (int j = 0; j < lin.n_terms; j++) {
+            lin.t[j].coeffs = pi_lagrange_.as<Fr>() + (size_t)j * L;
+            lin.t[j].len = L;
+            lin.t[j].scalar = pi_values[j];
         }
-        L.constant = Fr::zero();
-        L.out = ev + 5 * N8;
-        L.out_len = N8;
-        poly_.linear_combination(L);
+        lin.constant = Fr::zero();
+        lin.out = ev + 5 * L;
+        lin.out_len = L;
+        poly_.linear_combination(lin);
     }
     QuotientArgs q;
     q.z = ev;
-    q.a = ev + N8;
-    q.b = ev + 2 * N8;
-    q.c = ev + 3 * N8;
-    q.d = ev + 4 * N8;
-    q.pi = ev + 5 * N8;
+    q.a = ev + L;
+    q.b = ev + 2 * L;
+    q.c = ev + 3 * L;
+    q.d = ev + 4 * L;
+    q.pi = ev + 5 * L;
     for (int k = 0; k < N_SEL; k++) q.sel[k] = key_eval8n(k);
     q.linear = key_eval8n(N_SEL);
     q.l1 = key_eval8n(N_SEL + 1);
-    q.out = t_out;
+    q.out = shared() ? ev + 6 * L : t_out;
     q.alpha = ch[0];
     q.alpha_sq = Fr::sqr(ch[0]);
     q.beta = ch[1];
@@ -629,10 +662,18 @@ uint64_t Prover::quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4],
     q.fixed_ch = ch[5];
     q.var_ch = ch[6];
     for (int i = 0; i < 8; i++) q.vh_inv[i] = vh_inv_[i];
-    q.n8 = (uint32_t)N8;
+    q.n8 = (uint32_t)L;
+    // a slice i = rank + world * k keeps the rotation by 8 local: world divides 8
+    q.world = key_world_;
+    q.first = key_rank_;
+    q.rot = 8 / key_world_;
     q.widgets = widgets_;
     poly_.quotient(q);
-    ntt_.transform(NTT_COSET_IFFT, t_out, N8, t_out, lg8);  // quotient_poly.rs:97
+    // quotient_poly.rs:97
+    if (shared())
+        ntt_.inverse_sharded(true, q.out, t_out, lg8, coll_);
+    else
+        ntt_.transform(NTT_COSET_IFFT, t_out, N8, t_out, lg8);
     return poly_.length_without_leading_zeros(t_out, N8);    // Polynomial::from_coefficients_vec
 }
 

@@ -50,6 +50,14 @@ class Prover {
     // all-gather m partial sums of 18 limbs each into all[rank][m][18]; nullptr switches sharding off.
     typedef int (*ExchangeFn)(void *user, const uint64_t *mine, size_t m, uint64_t *all);
     void set_sharding(uint64_t shard_base, uint64_t total_points, uint32_t world, ExchangeFn fn, void *user);
+    // Shares the 8n-point work of a proof among `world` contexts (one per GPU): every key vector over the 8n coset and
+    // every round polynomial's coset evaluations are held as the cyclic slice i = rank + world * k, the quotient is
+    // evaluated on that slice, and its inverse transform goes through the caller's all-to-all and all-gather
+    // (NttEngine::inverse_sharded).  Takes effect at the next load_key; 2, 4 or 8 ranks, otherwise the 8n work stays
+    // replicated.  fn == nullptr switches it off.
+    void set_collective(uint32_t rank, uint32_t world, Collective::Fn fn, void *user);
+    // number of elements of one key vector over the coset held by this context: 8n, or 8n / world when shared
+    size_t eval_len() const { return ev_len_; }
     bool loaded() const { return n_ != 0; }
     uint32_t n() const { return n_; }
     const AffineOut *selector_comms() const { return sel_comms_; }
@@ -78,6 +86,10 @@ class Prover {
     void blind_poly(const Fr *evals_dev, int hiding_degree, const Fr *blinders, Fr *out_dev);
     void build_l1_and_vanishing(bool with_linear);
     void build_pi_lagrange();
+    // coset_fft over the 8n domain (fft/domain.rs:176-185) of a polynomial held in full: all 8n evaluations, or this
+    // context's cyclic slice of them when the key was loaded under set_collective
+    void coset_fft_8n(const Fr *coeffs, uint64_t len, Fr *out);
+    bool shared() const { return key_world_ > 1; }
 
     hipStream_t stream_;
     NttEngine &ntt_;
@@ -87,6 +99,9 @@ class Prover {
     void *exchange_user_ = nullptr;
     uint64_t shard_base_ = 0, total_points_ = 0;
     uint32_t world_ = 1;
+    Collective coll_;                     // as set by set_collective
+    uint32_t key_world_ = 1, key_rank_ = 0;   // how the loaded key's coset vectors are dealt out
+    size_t ev_len_ = 0;
     uint32_t n_ = 0, log_n_ = 0;
     uint64_t constraints_ = 0;
     uint64_t vk_n_ = 0;   // VerifierKey.n: the constraint count for a compiled key (compiler.rs:211-212), the stored value

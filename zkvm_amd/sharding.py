@@ -10,6 +10,8 @@ import numpy as np
 
 from . import api
 
+ALL_TO_ALL, ALL_GATHER = 0, 1
+
 
 def shard_range(n, rank, world):
     """Contiguous balanced split of [0, n): -> (base, length); the first n % world ranks get one more."""
@@ -85,3 +87,67 @@ def enable_prover_sharding(ctx, shard_base, total_points, device=None):
     ctx._check(ctx._lib.zkgpu_prover_set_sharding(ctx._h, int(shard_base), int(total_points), int(world),
                                                   C.cast(exchange, C.c_void_p), None))
     return exchange
+
+
+def collective_on_tensors(op, send, recv, stage_on_host=False):
+    """One collective of the sharded transforms on byte tensors of the default process group: ALL_TO_ALL (send holds
+    world blocks, block r for rank r; recv receives block r from rank r) or ALL_GATHER (send holds one block; recv
+    receives all ranks' blocks in rank order).  With stage_on_host the data travels through host copies (gloo)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    if stage_on_host:
+        s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+    else:
+        s, r = send, recv
+    if op == ALL_TO_ALL:
+        dist.all_to_all_single(r, s)
+    elif op == ALL_GATHER:
+        if stage_on_host or not r.is_cuda:
+            dist.all_gather(list(r.chunk(world)), s)
+        else:
+            dist.all_gather_into_tensor(r, s)
+    else:
+        raise ValueError("unknown collective %r" % (op,))
+    if stage_on_host:
+        recv.copy_(r)
+    return recv
+
+
+class _DeviceBytes:
+    """A range of device memory owned by the library, presented through __cuda_array_interface__ so that torch wraps
+    it as a tensor without copying."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2,
+                                         "strides": None}
+
+
+def enable_collectives(ctx, device=None):
+    """Registers torch.distributed as the exchange of this context's sharded transforms (zkgpu_set_collective): RCCL
+    on the device buffers when the default process group's backend is nccl (pass its CUDA device), host-staged
+    otherwise.  Returns the callback object, which must stay alive as long as the context."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    cuda = torch.device("cuda", ctx.device)
+    on_host = device is None
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+    def collective(_user, op, send_ptr, recv_ptr, block_bytes):
+        try:
+            send_len = block_bytes * (world if op == ALL_TO_ALL else 1)
+            send = torch.as_tensor(_DeviceBytes(send_ptr, send_len), device=cuda)
+            recv = torch.as_tensor(_DeviceBytes(recv_ptr, block_bytes * world), device=cuda)
+            collective_on_tensors(op, send, recv, stage_on_host=on_host)
+            torch.cuda.synchronize(cuda)      # the library reads recv on its own stream next
+            return 0
+        except Exception:   # never unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    ctx._collective_cb = collective
+    ctx._check(ctx._lib.zkgpu_set_collective(ctx._h, int(rank), int(world), C.cast(collective, C.c_void_p), None))
+    return collective

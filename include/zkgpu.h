@@ -309,6 +309,32 @@ int zkgpu_prove(zkgpu_ctx *ctx, const uint64_t *wires, const uint64_t *public_in
                 const uint64_t *blinders14, uint64_t *out_comms_xy, uint8_t *out_comms_infinity, uint64_t *out_evals15,
                 uint64_t *out_challenges10, float *timings8);
 
+/* ---- circuit front-end of the reference's own workload (host only, no context) --------------------------------------
+ * OpeningCircuit (merkle-plonk/src/lib.rs:117-131) over opening_gadget (poseidon-merkle/src/zk.rs:16-102) and the
+ * Hades permutation gadget (coset-poseidon/src/hades/permutation/gadget.rs:39-106), built gate by gate as the
+ * reference's Composer does (plonk/src/composer.rs:76-131,139-195,451-501,705-716,936-962), for k openings of trees
+ * of the same height in ONE circuit (one public root per opening), written straight into the tables
+ * zkgpu_prover_key_load and zkgpu_prove consume.  The reference proves one opening per circuit
+ * (merkle-plonk/src/lib.rs:275-332); k = 1 gives exactly that circuit, larger k the batch circuit of many openings.
+ *
+ * All field elements are Montgomery limbs.  leaves: k elements; branches: k x height x 4 sibling hashes, level 0
+ * right under the root (coset-merkle/src/opening.rs:19-23); positions: k x height child indexes below 4; roots: the k
+ * public roots; arc / mds: the 340 round constants and the 5 x 5 MDS matrix of coset-poseidon/assets; tag: the sponge's
+ * tag for four absorbed values and one squeezed under Domain::Merkle4 (coset-poseidon/src/hash.rs:15-67).
+ * Outputs for the power of two n returned by the _size call: selectors 15 x n (the four sigma rows left zero: they are
+ * the values of build_permutation_lagrange_mapping at sigma_map, composer/permutation.rs:111-141), sigma_map 4 x n
+ * with entry = column * n + gate (compute_sigma_permutations, :78-109), wires 4 x n gate-wise witness values, and the
+ * k public-input gate indexes with their values.  `threads` host threads generate the openings in parallel. */
+int zkgpu_merkle_batch_circuit_size(uint32_t height, uint32_t k, uint64_t *constraints, uint64_t *n);
+int zkgpu_merkle_batch_circuit(uint32_t height, uint32_t k, const uint64_t *leaves, const uint64_t *branches,
+                               const uint8_t *positions, const uint64_t *roots, const uint64_t *arc, const uint64_t *mds,
+                               const uint64_t tag[4], uint64_t n, uint64_t *selectors, uint64_t *sigma_map, uint64_t *wires,
+                               uint64_t *pi_indexes, uint64_t *public_inputs, uint32_t threads);
+/* Hash::digest(Domain::Merkle4, four values) (coset-poseidon/src/hash.rs:144-148 over hades/permutation/scalar.rs:33-67)
+ * for `count` groups of four inputs: the node hash of the Poseidon-Merkle tree (poseidon-merkle/src/lib.rs:133-160). */
+int zkgpu_poseidon_merkle4(const uint64_t *inputs, size_t count, const uint64_t *arc, const uint64_t *mds, const uint64_t tag[4],
+                           uint64_t *out);
+
 /* Transcript::new(label); append_message(msg_label, msg); challenge_bytes(ch_label, out): conformance hook for the
  * host-side Merlin implementation the prover's transcript uses (plonk/src/transcript.rs). Host-only. */
 int zkgpu_transcript_challenge(const char *label, const char *msg_label, const uint8_t *msg, size_t msg_len,

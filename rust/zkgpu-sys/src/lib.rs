@@ -122,6 +122,13 @@ extern "C" {
     pub fn zkgpu_prove(ctx: *mut zkgpu_ctx, wires: *const u64, public_inputs: *const u64, n_pi: usize,
                        blinders14: *const u64, out_comms_xy: *mut u64, out_comms_infinity: *mut u8,
                        out_evals15: *mut u64, out_challenges10: *mut u64, timings8: *mut f32) -> c_int;
+    pub fn zkgpu_merkle_batch_circuit_size(height: u32, k: u32, constraints: *mut u64, n: *mut u64) -> c_int;
+    pub fn zkgpu_merkle_batch_circuit(height: u32, k: u32, leaves: *const u64, branches: *const u64, positions: *const u8,
+                                      roots: *const u64, arc: *const u64, mds: *const u64, tag: *const u64, n: u64,
+                                      selectors: *mut u64, sigma_map: *mut u64, wires: *mut u64, pi_indexes: *mut u64,
+                                      public_inputs: *mut u64, threads: u32) -> c_int;
+    pub fn zkgpu_poseidon_merkle4(inputs: *const u64, count: usize, arc: *const u64, mds: *const u64, tag: *const u64,
+                                  out: *mut u64) -> c_int;
     pub fn zkgpu_transcript_challenge(label: *const c_char, msg_label: *const c_char, msg: *const u8, msg_len: usize,
                                       ch_label: *const c_char, out: *mut u8, out_len: usize) -> c_int;
 }

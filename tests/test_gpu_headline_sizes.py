@@ -170,3 +170,50 @@ def test_msm_2_24_distinct_points_properties(orc):
         assert inf3 == 1
     finally:
         c.close()
+
+
+@pytest.mark.timeout(900)
+def test_merkle_batch_circuit_2_24_gates_proof_accepted(orc):
+    """The reference's largest configuration with its own gate mix: 519 openings of a height-32 Poseidon-Merkle tree in
+    one circuit (16.76 M gates, n = 2^24, 8n = 2^27-point transforms, 519 public roots), generated by the library's
+    native front-end, proved on one GPU and accepted by the restated verifier with its pairing; a tampered proof is
+    refused.  The CPU oracle would need about half an hour for this proof."""
+    import torch
+    import plonk_check
+    import zkvm_amd
+    from zkvm_amd import api, circuits, poseidon as P
+    height, k = 32, 519
+    tree = P.Tree(height, native=True)
+    rng = np.random.default_rng(24)
+    spots = sorted({int(p) for p in rng.integers(0, 1 << 62, k + 8)})[:k]      # 4^32 = 2^64 leaf positions
+    for p in spots:
+        tree.insert(p, P.hash_to_scalar(p.to_bytes(8, "little")))
+    openings = [tree.opening(p) for p in spots]
+    leaves = [tree.leaves[p] for p in spots]
+    assert openings[7].verify(leaves[7]) and not openings[7].verify(leaves[8])
+    circ = P.batch_opening_circuit(openings, leaves, threads=16)
+    n = circ["n"]
+    assert n == 1 << 24 and circ["constraints"] == 4 + k * 32289 and len(circ["pi_indexes"]) == k
+    ctx = zkvm_amd.Context(0)
+    try:
+        tau = M.random_fr_mont(1, seed=4040)[0]
+        gxy, _ = orc.g1_to_affine(orc.g1_generator())
+        ctx.srs_setup(tau, gxy, n + 7)
+        circuits.fill_sigma_rows(circ, ctx)
+        gp = api.Prover(ctx, n, circ["constraints"], circ["selectors"].reshape(-1, 4), b"merkle-batch", circ["pi_indexes"])
+        sxy, sinf = gp.selector_commitments()
+        circ["selectors"] = None
+        wires = torch.from_numpy(circ["wires"].reshape(-1, 4).view(np.int64)).cuda()
+        proof = gp.prove(wires, circ["public_inputs"], circuits.random_blinders(24))
+        del wires
+        tau_int = M.fr_from_mont(tau)
+        h, tau_h = plonk_check.opening_key_g2(tau_int)
+        assert plonk_check.verify(n, circ["constraints"], b"merkle-batch", proof, sxy, sinf, circ["public_inputs"],
+                                  circ["pi_indexes"], gxy, h, tau_h, orc)
+        bad = dict(proof)
+        bad["evals"] = proof["evals"].copy()
+        bad["evals"][3, 0] ^= np.uint64(1)
+        assert not plonk_check.verify(n, circ["constraints"], b"merkle-batch", bad, sxy, sinf, circ["public_inputs"],
+                                      circ["pi_indexes"], gxy, h, tau_h, orc)
+    finally:
+        ctx.close()

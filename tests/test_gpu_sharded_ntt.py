@@ -111,16 +111,33 @@ def _prove_worker(rank, world, port, n, seed, widgets, out_dir):
     dist.destroy_process_group()
 
 
+def _merkle_batch(k, height, seed):
+    from zkvm_amd import poseidon as P
+    tree = P.Tree(height, native=True)
+    rng = np.random.default_rng(seed)
+    spots = sorted({int(p) for p in rng.integers(0, tree.capacity(), k + 4)})[:k]
+    for p in spots:
+        tree.insert(p, P.hash_to_scalar(p.to_bytes(8, "little")))
+    return P.batch_opening_circuit([tree.opening(p) for p in spots], [tree.leaves[p] for p in spots], threads=4)
+
+
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,log_n", [(2, 10), (2, 14), (4, 10), (8, 6)])
+@pytest.mark.parametrize("world,log_n", [(2, 10), (2, 14), (4, 10), (8, 6), (4, "merkle")])
 def test_shared_proof_equals_oracle(tmp_path, orc, world, log_n):
     """zkgpu_set_collective + zkgpu_prover_set_sharding: every rank holds 1 / world of the ProverKey's coset vectors and
-    of the SRS, evaluates the quotient on its slice, and all ranks return the oracle's proof."""
+    of the SRS, evaluates the quotient on its slice, and all ranks return the oracle's proof.  The "merkle" case is the
+    reference's sharded configuration in small: three Poseidon-Merkle openings in one circuit (2^14 rows, three public
+    inputs) on four ranks."""
     import torch.multiprocessing as mp
     from zkvm_amd import circuits
-    n = 1 << log_n
-    seed = 40 + log_n
-    c = circuits.arithmetic_circuit(n, seed=seed)
+    if log_n == "merkle":
+        c = _merkle_batch(3, 4, seed=9)
+        n, log_n, seed = c["n"], c["n"].bit_length() - 1, 77
+        assert n == 1 << 14
+    else:
+        n = 1 << log_n
+        seed = 40 + log_n
+        c = circuits.arithmetic_circuit(n, seed=seed)
     c["selectors"][11:15] = np.stack([orc.sigma_to_lagrange(c["sigma_map"][k]) for k in range(4)])
     np.savez(os.path.join(str(tmp_path), "circuit.npz"), constraints=c["constraints"], selectors=c["selectors"], wires=c["wires"],
              public_inputs=c["public_inputs"], pi_indexes=np.array(c["pi_indexes"]))

@@ -261,3 +261,80 @@ def test_gpu_merkle_opening_height_17(orc):
     for key in ("challenges", "evals", "comms_inf", "comms"):
         assert np.array_equal(got[key], want[key]), key
     assert _accepted(orc, circ, op, srs, tau, b"merkle", got)
+
+
+# ---- the native generator (host code of the library: no GPU needed) -------------------------------------------------
+def _tree_with_openings(height, count, seed):
+    from zkvm_amd import poseidon as P
+    tree = P.Tree(height)
+    rng = np.random.default_rng(seed)
+    spots = sorted({int(p) for p in rng.integers(0, tree.capacity(), count + 3)})[:count]
+    for p in spots:
+        tree.insert(p, P.digest(P.Domain.OTHER, [p, seed])[0])
+    return tree, spots
+
+
+def test_native_merkle4_digest_equals_the_mirror():
+    from zkvm_amd import poseidon as P
+    groups = [seeded_state(s)[:4] for s in range(5)] + [[0, 0, 0, 0], [R - 1] * 4]
+    assert P.merkle4_native(groups) == [P.digest(P.Domain.MERKLE4, g)[0] for g in groups]
+
+
+@pytest.mark.parametrize("height", [1, 3, 8])
+def test_native_circuit_of_one_opening_equals_the_composer(height):
+    """k = 1: gate for gate the tables of the reference's OpeningCircuit as the Python Composer builds them -
+    selectors, the copy-constraint permutation, the wire columns and the public input."""
+    from zkvm_amd import poseidon as P
+    tree, spots = _tree_with_openings(height, 2, seed=height)
+    opening, leaf = tree.opening(spots[1]), tree.leaves[spots[1]]
+    want = P.opening_circuit(opening, leaf).tables()
+    got = P.batch_opening_circuit([opening], [leaf], threads=2)
+    assert got["n"] == want["n"] and got["constraints"] == want["constraints"] and got["pi_indexes"] == want["pi_indexes"]
+    for key in ("selectors", "sigma_map", "wires", "public_inputs"):
+        assert np.array_equal(got[key], want[key]), key
+
+
+def test_native_batch_circuit_equals_the_composer_on_several_openings(orc):
+    """k openings on one Composer (the loop of merkle-plonk/src/lib.rs:275-332 folded into one circuit): the native
+    generator's blocks against the gate-by-gate mirror, a false leaf breaks exactly its own block, and the CPU prover's
+    proof of the batch circuit is accepted."""
+    from zkvm_amd import circuits, poseidon as P
+    from zkvm_amd.composer import Composer, Constraint
+    tree, spots = _tree_with_openings(2, 5, seed=21)
+    openings = [tree.opening(p) for p in spots]
+    leaves = [tree.leaves[p] for p in spots]
+    c = Composer.initialized()
+    for o, leaf in zip(openings, leaves):
+        root = P.opening_gadget(c, o, c.append_witness(leaf))
+        c.append_gate(Constraint().left(-1).a(root).public(o.root))
+    assert gates_hold(c)
+    want = c.tables()
+    for threads in (1, 3, 16):
+        got = P.batch_opening_circuit(openings, leaves, threads=threads)
+        assert got["n"] == want["n"] and got["constraints"] == want["constraints"] and got["pi_indexes"] == want["pi_indexes"]
+        for key in ("selectors", "sigma_map", "wires", "public_inputs"):
+            assert np.array_equal(got[key], want[key]), (key, threads)
+    assert [M.fr_from_mont(v) for v in got["public_inputs"]] == [tree.root()] * 5
+    op, srs, tau = _prover(orc, got, b"merkle-batch")
+    proof = op.prove(got["wires"], got["public_inputs"], circuits.random_blinders(5))
+    assert proof["rc"] == 0 and _accepted(orc, got, op, srs, tau, b"merkle-batch", proof)
+    bad = P.batch_opening_circuit(openings, leaves[:2] + [leaves[2] + 1] + leaves[3:])
+    block = (want["constraints"] - 4) // 5
+    diff = np.nonzero((bad["wires"] != want["wires"]).any(axis=(0, 2)))[0]
+    assert diff.size and diff.min() >= 4 + 2 * block and diff.max() < 4 + 3 * block
+    op, _, _ = _prover(orc, bad, b"merkle-batch")
+    assert op.prove(bad["wires"], bad["public_inputs"], circuits.random_blinders(5))["rc"] == 2
+
+
+def test_native_circuit_argument_checks():
+    import ctypes as C
+    from zkvm_amd import _lib
+    lib = _lib.lib()
+    gates, n = C.c_uint64(0), C.c_uint64(0)
+    assert lib.zkgpu_merkle_batch_circuit_size(0, 1, C.byref(gates), C.byref(n)) == -1
+    assert lib.zkgpu_merkle_batch_circuit_size(32, 0, C.byref(gates), C.byref(n)) == -1
+    assert lib.zkgpu_merkle_batch_circuit_size(32, 1, C.byref(gates), C.byref(n)) == 0
+    assert gates.value == 32293 and n.value == 1 << 15          # one height-32 opening: the reference's workload
+    assert lib.zkgpu_merkle_batch_circuit_size(32, 519, C.byref(gates), C.byref(n)) == 0
+    assert n.value == 1 << 24 and gates.value > (1 << 24) - 32289
+    assert lib.zkgpu_merkle_batch_circuit_size(32, 1 << 20, C.byref(gates), C.byref(n)) == -4

@@ -259,10 +259,11 @@ class Tree:
     """Sparse ARITY-ary tree of the given height whose nodes carry Poseidon hashes: an inner node hashes its
     children under Domain::Merkle4 and a missing child counts as zero (poseidon-merkle/src/lib.rs:133-160)."""
 
-    def __init__(self, height):
+    def __init__(self, height, native=False):
         self.height = height
         self.leaves = {}
         self._nodes = None
+        self.native = native          # hash the inner nodes with the library's host code (same values, much faster)
 
     def capacity(self):
         return ARITY ** self.height
@@ -279,11 +280,10 @@ class Tree:
             levels = [None] * (self.height + 1)
             levels[self.height] = dict(self.leaves)
             for h in reversed(range(self.height)):
-                parents = {}
-                for index in {i // ARITY for i in levels[h + 1]}:
-                    parents[index] = digest(Domain.MERKLE4,
-                                            [levels[h + 1].get(ARITY * index + k, 0) for k in range(ARITY)])[0]
-                levels[h] = parents
+                indexes = sorted({i // ARITY for i in levels[h + 1]})
+                groups = [[levels[h + 1].get(ARITY * index + k, 0) for k in range(ARITY)] for index in indexes]
+                hashes = merkle4_native(groups) if self.native else [digest(Domain.MERKLE4, g)[0] for g in groups]
+                levels[h] = dict(zip(indexes, hashes))
             self._nodes = levels
         return self._nodes
 
@@ -348,3 +348,73 @@ def permutation_circuit(input_state, expected_state):
     for got, want in zip(GadgetPermutation(composer).permute(inputs), expected):
         composer.assert_equal(got, want)
     return composer
+
+
+# ---- the native generator (zkvm_amd/csrc/frontend.hip) ---------------------------------------------------------------
+def _mont_table(values):
+    import numpy as np
+    from . import circuits
+    return circuits.ints_to_limbs([circuits.to_mont(v) for v in values])
+
+
+def _native_constants():
+    import numpy as np
+    arc = _mont_table([k for row in ROUND_CONSTANTS for k in row])
+    mds = _mont_table([m for row in MDS_MATRIX for m in row])
+    tag = _mont_table([hash_to_scalar(tag_input(_io_pattern(Domain.MERKLE4, [[0] * ARITY], 1), Domain.MERKLE4))])
+    return np.ascontiguousarray(arc), np.ascontiguousarray(mds), np.ascontiguousarray(tag)
+
+
+def merkle4_native(groups):
+    """Hash::digest(Domain::Merkle4, ...) of many groups of four canonical integers by the library's host code
+    -> list of canonical integers.  Same values as digest(); a tree of many leaves builds much faster with it."""
+    import numpy as np
+    from . import _lib, circuits
+    flat = [int(v) % R for g in groups for v in g]
+    assert len(flat) % ARITY == 0
+    count = len(flat) // ARITY
+    inp = np.ascontiguousarray(_mont_table(flat))
+    out = np.zeros((count, 4), dtype=np.uint64)
+    arc, mds, tag = _native_constants()
+    rc = _lib.lib().zkgpu_poseidon_merkle4(inp.ctypes.data, count, arc.ctypes.data, mds.ctypes.data, tag.ctypes.data,
+                                           out.ctypes.data)
+    if rc != 0:
+        raise _lib.ZkGpuError(rc, "poseidon_merkle4")
+    return [v * circuits.MONT_INV % R for v in circuits.limbs_to_ints(out)]
+
+
+def batch_opening_circuit(openings, leaf_hashes, threads=8):
+    """One circuit proving k Merkle openings (trees of one height), each tied to its public root: the reference's
+    OpeningCircuit (merkle-plonk/src/lib.rs:117-131) repeated k times on one Composer, generated natively.  Returns
+    the circuit dict of Composer.tables(): for k = 1 the same arrays as opening_circuit(...).tables()."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    k = len(openings)
+    assert k >= 1 and len(leaf_hashes) == k
+    height = len(openings[0].branch)
+    assert all(len(o.branch) == height and len(o.positions) == height for o in openings)
+    lib = _lib.lib()
+    gates, n = C.c_uint64(0), C.c_uint64(0)
+    rc = lib.zkgpu_merkle_batch_circuit_size(height, k, C.byref(gates), C.byref(n))
+    if rc != 0:
+        raise _lib.ZkGpuError(rc, "merkle_batch_circuit_size")
+    n = int(n.value)
+    leaves = np.ascontiguousarray(_mont_table(leaf_hashes))
+    branches = np.ascontiguousarray(_mont_table([v for o in openings for level in o.branch for v in level]))
+    positions = np.ascontiguousarray([p for o in openings for p in o.positions], dtype=np.uint8)
+    roots = np.ascontiguousarray(_mont_table([o.root for o in openings]))
+    arc, mds, tag = _native_constants()
+    sel = np.zeros((15, n, 4), dtype=np.uint64)
+    sigma = np.zeros((4, n), dtype=np.uint64)
+    wires = np.zeros((4, n, 4), dtype=np.uint64)
+    pi_idx = np.zeros(k, dtype=np.uint64)
+    pi_val = np.zeros((k, 4), dtype=np.uint64)
+    rc = lib.zkgpu_merkle_batch_circuit(height, k, leaves.ctypes.data, branches.ctypes.data, positions.ctypes.data,
+                                        roots.ctypes.data, arc.ctypes.data, mds.ctypes.data, tag.ctypes.data, n,
+                                        sel.ctypes.data, sigma.ctypes.data, wires.ctypes.data, pi_idx.ctypes.data,
+                                        pi_val.ctypes.data, int(threads))
+    if rc != 0:
+        raise _lib.ZkGpuError(rc, "merkle_batch_circuit")
+    return dict(n=n, constraints=int(gates.value), selectors=sel, sigma_map=sigma, wires=wires, public_inputs=pi_val,
+                pi_indexes=[int(i) for i in pi_idx])

@@ -298,6 +298,20 @@ int zkgpu_perm_z(zkgpu_ctx *ctx, uint32_t n, const uint64_t *wires, const uint64
 int zkgpu_poly_eval(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, const uint64_t x[4], uint64_t out[4]);
 int zkgpu_poly_ruffini(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, const uint64_t root[4], uint64_t *out);
 
+/* build_linearization_polynomial (plonk/src/proof_system/linearization_poly.rs:146-234) for the loaded key.  `polys`
+ * packs the coefficient vectors z, t_low, t_mid, t_high, t_fourth back to back with lens[5]; challenges7 = alpha beta
+ * gamma range logic fixed_base var_base; evals15 in ProofEvaluations field order (linearization_poly.rs:29-74);
+ * public_inputs = the sparse list the reference hands to compute_barycentric_eval (proof_system/proof.rs:511-561).
+ * r_out (room for r_cap >= max(n, lens) coefficients) receives r(X); *r_len its length once leading zeros are dropped. */
+int zkgpu_linearization(zkgpu_ctx *ctx, const uint64_t *polys, const size_t lens[5], const uint64_t *challenges7,
+                        const uint64_t z_challenge[4], const uint64_t *evals15, const uint64_t *public_inputs, size_t n_pi,
+                        uint64_t *r_out, size_t r_cap, size_t *r_len);
+/* CommitKey::compute_aggregate_witness (plonk/src/commitment_scheme/kzg10/key.rs:131-146): (sum_j v^j p_j) / (X - point)
+ * with the remainder dropped, for up to 18 polynomials packed back to back with lens[n_polys].  out receives at most
+ * max(lens) - 1 coefficients, *out_len the count once leading zeros are dropped.  Needs no key. */
+int zkgpu_aggregate_witness(zkgpu_ctx *ctx, const uint64_t *polys, const size_t *lens, size_t n_polys, const uint64_t point[4],
+                            const uint64_t v[4], uint64_t *out, size_t *out_len);
+
 /* Prover::prove (plonk/src/compiler/prover.rs:210-509) for the loaded key.  `wires` holds the 4 x n gate-wise
  * values a, b, c, d (host memory, or a device pointer when the witness is already in HBM); `public_inputs` the n_pi public input values in index order; `blinders14` the 14 scalars
  * the reference draws from its RNG, in draw order a(2) b(2) c(2) d(2) z(3) b12 b13 b14.  Outputs: the 11

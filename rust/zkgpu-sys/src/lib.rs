@@ -119,6 +119,11 @@ extern "C" {
     pub fn zkgpu_poly_eval(ctx: *mut zkgpu_ctx, coeffs: *const u64, len: usize, x: *const u64, out: *mut u64) -> c_int;
     pub fn zkgpu_poly_ruffini(ctx: *mut zkgpu_ctx, coeffs: *const u64, len: usize, root: *const u64, out: *mut u64)
                               -> c_int;
+    pub fn zkgpu_linearization(ctx: *mut zkgpu_ctx, polys: *const u64, lens: *const usize, challenges7: *const u64,
+                               z_challenge: *const u64, evals15: *const u64, public_inputs: *const u64, n_pi: usize,
+                               r_out: *mut u64, r_cap: usize, r_len: *mut usize) -> c_int;
+    pub fn zkgpu_aggregate_witness(ctx: *mut zkgpu_ctx, polys: *const u64, lens: *const usize, n_polys: usize,
+                                   point: *const u64, v: *const u64, out: *mut u64, out_len: *mut usize) -> c_int;
     pub fn zkgpu_prove(ctx: *mut zkgpu_ctx, wires: *const u64, public_inputs: *const u64, n_pi: usize,
                        blinders14: *const u64, out_comms_xy: *mut u64, out_comms_infinity: *mut u8,
                        out_evals15: *mut u64, out_challenges10: *mut u64, timings8: *mut f32) -> c_int;

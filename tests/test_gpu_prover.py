@@ -143,6 +143,45 @@ def test_quotient(ctx, orc, srs, log_n):
     assert want.shape[0] <= 4 * n   # the circuit is satisfied: the division is exact (degree 4n - 5)
 
 
+@pytest.mark.parametrize("log_n", [3, 6, 11])
+def test_linearization(ctx, orc, srs, log_n):
+    """build_linearization_polynomial (linearization_poly.rs:146-234) on its own: random round polynomials, quotient
+    parts of ragged lengths, evaluations and challenges against the oracle's restatement, coefficient for coefficient."""
+    n = 1 << log_n
+    c = _circuit(orc, n, seed=60 + log_n)
+    gp, op = _provers(ctx, orc, srs, c)
+    for trial, t4_len in enumerate((n + 6, 3, 0)):
+        z = M.random_fr_mont(n + 3, seed=61 + trial)
+        parts = [M.random_fr_mont(k, seed=62 + 10 * trial + j) for j, k in enumerate((n + 1, n + 1, n + 1, t4_len))]
+        ch = M.random_fr_mont(7, seed=63 + trial)
+        z_ch = M.random_fr_mont(1, seed=64 + trial)[0]
+        evals = M.random_fr_mont(15, seed=65 + trial)
+        want = op.linearization(z, *parts, ch, z_ch, evals, c["public_inputs"])
+        got = gp.linearization(z, *parts, ch, z_ch, evals, c["public_inputs"])
+        assert got.shape == want.shape and np.array_equal(got, want), (log_n, trial)
+    # a z polynomial with leading zeros: its degree picks the domain of L_1(z) (permutation/proverkey.rs:156)
+    z = M.random_fr_mont(n + 3, seed=70)
+    z[n // 2:] = 0
+    want = op.linearization(z, *parts, ch, z_ch, evals, c["public_inputs"])
+    got = gp.linearization(z, *parts, ch, z_ch, evals, c["public_inputs"])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("lens", [[5], [1], [40, 7, 64, 3], [1 << 13, (1 << 13) + 3, 100], [300] * 8])
+def test_aggregate_witness(ctx, orc, lens):
+    """CommitKey::compute_aggregate_witness (kzg10/key.rs:131-146): powers of v over ragged polynomials, then the
+    division by (X - z) with the remainder dropped."""
+    from zkvm_amd import api
+    polys = [M.random_fr_mont(k, seed=80 + i + k) for i, k in enumerate(lens)]
+    point, v = M.random_fr_mont(2, seed=81 + len(lens))
+    want = orc.aggregate_witness(polys, point, v)
+    got = api.aggregate_witness(ctx, polys, point, v)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    # the point zero: the quotient is a shift
+    zero = np.zeros(4, np.uint64)
+    assert np.array_equal(api.aggregate_witness(ctx, polys, zero, v), orc.aggregate_witness(polys, zero, v))
+
+
 @pytest.mark.parametrize("log_n,seed", [(3, 1), (4, 2), (7, 3), (10, 4), (12, 5)])
 def test_prove(ctx, orc, srs, log_n, seed):
     from zkvm_amd import api, circuits

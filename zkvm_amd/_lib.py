@@ -89,6 +89,8 @@ SIGNATURES = {
     "zkgpu_perm_z": (C.c_int, [_P, C.c_uint32, _P, _P, _P, _P, _P]),
     "zkgpu_poly_eval": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
     "zkgpu_poly_ruffini": (C.c_int, [_P, _P, C.c_size_t, _P, _P]),
+    "zkgpu_linearization": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "zkgpu_aggregate_witness": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.POINTER(C.c_size_t)]),
     "zkgpu_prove": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, _P, _P, _P]),
     "zkgpu_merkle_batch_circuit_size": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "zkgpu_merkle_batch_circuit": (C.c_int, [C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, _P, C.c_uint64, _P, _P, _P, _P, _P,

@@ -428,6 +428,21 @@ class Prover:
                                                      out.ctypes.data, C.byref(t_len)))
         return out[:t_len.value].copy()
 
+    def linearization(self, z, t_low, t_mid, t_high, t_fourth, challenges7, z_challenge, evals15, public_inputs):
+        """build_linearization_polynomial -> coefficient array with leading zeros dropped."""
+        polys = [_np_u64(p, 4) for p in (z, t_low, t_mid, t_high, t_fourth)]
+        lens = (C.c_size_t * 5)(*[p.shape[0] for p in polys])
+        packed = np.ascontiguousarray(np.concatenate(polys, axis=0))
+        pis = _np_u64(public_inputs, 4)
+        cap = max([self.n] + [p.shape[0] for p in polys])
+        out = np.zeros((cap, 4), dtype=np.uint64)
+        r_len = C.c_size_t(0)
+        self.ctx._check(self.ctx._lib.zkgpu_linearization(
+            self.ctx._h, packed.ctypes.data, lens, _np_u64(challenges7, 4).ctypes.data, _np_u64(z_challenge, 4).ctypes.data,
+            _np_u64(evals15, 4).ctypes.data, pis.ctypes.data if pis.size else None, pis.shape[0], out.ctypes.data, cap,
+            C.byref(r_len)))
+        return out[:r_len.value].copy()
+
     def prove(self, wires, public_inputs, blinders14, timings=False):
         if _is_torch(wires):
             assert wires.is_cuda and wires.is_contiguous() and wires.numel() == 16 * self.n
@@ -477,6 +492,19 @@ def poly_ruffini(ctx, coeffs, root):
     ctx._check(ctx._lib.zkgpu_poly_ruffini(ctx._h, c.ctypes.data if c.size else None, c.shape[0],
                                            _np_u64(root, 4).ctypes.data, out.ctypes.data if out.size else None))
     return out
+
+
+def aggregate_witness(ctx, polys, point, v):
+    """CommitKey::compute_aggregate_witness -> coefficient array with leading zeros dropped."""
+    arrs = [_np_u64(p, 4) for p in polys]
+    lens = (C.c_size_t * len(arrs))(*[a.shape[0] for a in arrs])
+    packed = np.ascontiguousarray(np.concatenate(arrs, axis=0)) if arrs else np.zeros((0, 4), np.uint64)
+    cap = max([a.shape[0] for a in arrs] + [1])
+    out = np.zeros((cap, 4), dtype=np.uint64)
+    n_out = C.c_size_t(0)
+    ctx._check(ctx._lib.zkgpu_aggregate_witness(ctx._h, packed.ctypes.data, lens, len(arrs), _np_u64(point, 4).ctypes.data,
+                                                _np_u64(v, 4).ctypes.data, out.ctypes.data, C.byref(n_out)))
+    return out[:n_out.value].copy()
 
 
 def transcript_challenge(label, msg_label, msg, ch_label, n):

@@ -748,6 +748,81 @@ int zkgpu_poly_ruffini(zkgpu_ctx *ctx, const uint64_t *coeffs, size_t len, const
     });
 }
 
+int zkgpu_linearization(zkgpu_ctx *ctx, const uint64_t *polys, const size_t lens[5], const uint64_t *challenges7,
+                        const uint64_t z_challenge[4], const uint64_t *evals15, const uint64_t *public_inputs, size_t n_pi,
+                        uint64_t *r_out, size_t r_cap, size_t *r_len) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(ctx->prover->loaded(), ZKGPU_ERR_NOT_LOADED, "no prover key loaded");
+        ZK_REQUIRE(polys && lens && challenges7 && z_challenge && evals15 && r_out && r_len && (public_inputs || n_pi == 0),
+                   ZKGPU_ERR_INVALID_ARG, "linearization: null argument");
+        const size_t n = ctx->prover->n();
+        size_t total = 0, longest = n;
+        for (int i = 0; i < 5; i++) {
+            total += lens[i];
+            if (lens[i] > longest) longest = lens[i];
+        }
+        ZK_REQUIRE(r_cap >= longest, ZKGPU_ERR_INVALID_ARG, "linearization: the output holds fewer coefficients than the longest term");
+        ctx->stage_a.reserve((total + 1) * sizeof(Fr));
+        ctx->stage_b.reserve(longest * sizeof(Fr));
+        if (total) ZK_HIP(hipMemcpyAsync(ctx->stage_a.p, polys, total * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        const Fr *base = ctx->stage_a.as<Fr>();
+        const Fr *ptr[5];
+        size_t off = 0;
+        for (int i = 0; i < 5; i++) {
+            ptr[i] = base + off;
+            off += lens[i];
+        }
+        Fr ch[7], z, e[15];
+        memcpy(ch, challenges7, sizeof ch);
+        memcpy(&z, z_challenge, sizeof z);
+        memcpy(e, evals15, sizeof e);
+        std::vector<Fr> pis(n_pi);
+        if (n_pi) memcpy(pis.data(), public_inputs, n_pi * sizeof(Fr));
+        const Fr *t_parts[4] = {ptr[1], ptr[2], ptr[3], ptr[4]};
+        const uint64_t t_lens[4] = {lens[1], lens[2], lens[3], lens[4]};
+        const uint64_t len = ctx->prover->linearization(ch, z, e, ptr[0], lens[0], t_parts, t_lens, pis, ctx->stage_b.as<Fr>(), longest);
+        // Polynomial arithmetic truncates leading zeros (fft/polynomial.rs:66-77)
+        const uint64_t eff = ctx->prover->poly().length_without_leading_zeros(ctx->stage_b.as<Fr>(), len);
+        if (eff) ZK_HIP(hipMemcpyAsync(r_out, ctx->stage_b.p, eff * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        *r_len = (size_t)eff;
+    });
+}
+
+int zkgpu_aggregate_witness(zkgpu_ctx *ctx, const uint64_t *polys, const size_t *lens, size_t n_polys, const uint64_t point[4],
+                            const uint64_t v[4], uint64_t *out, size_t *out_len) {
+    return guarded(ctx, [&] {
+        ZK_REQUIRE(polys && lens && point && v && out_len && n_polys >= 1 && n_polys <= (size_t)MAX_LIN_TERMS, ZKGPU_ERR_INVALID_ARG,
+                   "aggregate_witness: null argument or more than 18 polynomials");
+        size_t total = 0, longest = 0;
+        for (size_t i = 0; i < n_polys; i++) {
+            total += lens[i];
+            if (lens[i] > longest) longest = lens[i];
+        }
+        ZK_REQUIRE(out || longest <= 1, ZKGPU_ERR_INVALID_ARG, "aggregate_witness: null output");
+        ctx->stage_a.reserve((total + 1) * sizeof(Fr));
+        ctx->stage_b.reserve((2 * longest + 2) * sizeof(Fr));
+        if (total) ZK_HIP(hipMemcpyAsync(ctx->stage_a.p, polys, total * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        const Fr *ptr[MAX_LIN_TERMS];
+        uint64_t ls[MAX_LIN_TERMS];
+        size_t off = 0;
+        for (size_t i = 0; i < n_polys; i++) {
+            ptr[i] = ctx->stage_a.as<Fr>() + off;
+            ls[i] = lens[i];
+            off += lens[i];
+        }
+        Fr z, vv;
+        memcpy(&z, point, sizeof z);
+        memcpy(&vv, v, sizeof vv);
+        Fr *sum = ctx->stage_b.as<Fr>(), *wit = sum + longest + 1;
+        const uint64_t len = ctx->prover->aggregate_witness(ptr, ls, (int)n_polys, z, vv, sum, wit);
+        const uint64_t eff = len ? ctx->prover->poly().length_without_leading_zeros(wit, len) : 0;
+        if (eff) ZK_HIP(hipMemcpyAsync(out, wit, eff * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(hipStreamSynchronize(ctx->stream));
+        *out_len = (size_t)eff;
+    });
+}
+
 int zkgpu_prove(zkgpu_ctx *ctx, const uint64_t *wires, const uint64_t *public_inputs, size_t n_pi,
                 const uint64_t *blinders14, uint64_t *out_comms_xy, uint8_t *out_comms_infinity, uint64_t *out_evals15,
                 uint64_t *out_challenges10, float *timings8) {

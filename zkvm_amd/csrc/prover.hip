@@ -700,6 +700,107 @@ static Fr first_lagrange_coefficient(const Domain &d, const Fr &tau) {
     return Fr::mul(l, Fr::inv(Fr::sub(tau, Fr::one())));
 }
 
+// build_linearization_polynomial (linearization_poly.rs:146-272): scalars on the host from the 15 evaluations, one fused
+// pass over the polynomials on the device.  ch7 = alpha beta gamma range logic fixed var; e in ProofEvaluations order.
+// Returns the number of coefficients written to r_out (the longest term; leading zeros are not dropped here).
+uint64_t Prover::linearization(const Fr ch7[7], const Fr &z_ch, const Fr *e, const Fr *p_z, uint64_t z_len, const Fr *const t_parts[4],
+                               const uint64_t t_lens[4], const std::vector<Fr> &public_inputs, Fr *r_out, uint64_t r_cap) {
+    ZK_REQUIRE(loaded(), ZKGPU_ERR_NOT_LOADED, "linearization: no prover key loaded");
+    enum { A, B, C, D, AW, BW, DW, QARITH, QC, QL, QR, SG1, SG2, SG3, ZE };
+    typedef InlineMul M;
+    const uint64_t n = n_;
+    const Fr &alpha = ch7[0], &beta = ch7[1], &gamma = ch7[2], &range_ch = ch7[3], &logic_ch = ch7[4], &fixed_ch = ch7[5],
+             &var_ch = ch7[6];
+    const Domain domain = Domain::make(constraints_);
+    LinArgs L;
+    int k = 0;
+    uint64_t r_len = 0;
+    auto term = [&](const Fr *p, uint64_t len, const Fr &s) {
+        L.t[k].coeffs = p;
+        L.t[k].len = len;
+        L.t[k].scalar = s;
+        k++;
+        if (len > r_len) r_len = len;
+    };
+    // arithmetic/proverkey.rs:75-107
+    const Fr qa = e[QARITH];
+    term(key_poly(Q_M), n, Fr::mul(Fr::mul(e[A], e[B]), qa));
+    term(key_poly(Q_L), n, Fr::mul(e[A], qa));
+    term(key_poly(Q_R), n, Fr::mul(e[B], qa));
+    term(key_poly(Q_O), n, Fr::mul(e[C], qa));
+    term(key_poly(Q_F), n, Fr::mul(e[D], qa));
+    term(key_poly(Q_C), n, qa);
+    // range / logic / fixed-base / curve-addition compute_linearization
+    term(key_poly(Q_RANGE), n, Fr::mul(w_range_identity<M>(range_ch, e[A], e[B], e[C], e[D], e[DW]), range_ch));
+    term(key_poly(Q_LOGIC), n,
+         Fr::mul(w_logic_identity<M>(logic_ch, e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW], e[QC]), logic_ch));
+    term(key_poly(Q_FIXED), n,
+         Fr::mul(w_fixed_base_identity<M>(fixed_ch, e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW], e[QL], e[QR], e[QC]),
+                 fixed_ch));
+    term(key_poly(Q_VAR), n, Fr::mul(w_curve_add_identity<M>(var_ch, e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW]), var_ch));
+    // permutation/proverkey.rs:121-245
+    const Fr beta_z = Fr::mul(beta, z_ch);
+    Fr acc = Fr::add(Fr::add(e[A], beta_z), gamma);
+    acc = Fr::mul(acc, Fr::add(Fr::add(e[B], mul_small<7>(beta_z)), gamma));
+    acc = Fr::mul(acc, Fr::add(Fr::add(e[C], mul_small<13>(beta_z)), gamma));
+    acc = Fr::mul(acc, Fr::add(Fr::add(e[D], mul_small<17>(beta_z)), gamma));
+    acc = Fr::mul(acc, alpha);
+    Fr cacc = Fr::add(Fr::add(e[A], Fr::mul(beta, e[SG1])), gamma);
+    cacc = Fr::mul(cacc, Fr::add(Fr::add(e[B], Fr::mul(beta, e[SG2])), gamma));
+    cacc = Fr::mul(cacc, Fr::add(Fr::add(e[C], Fr::mul(beta, e[SG3])), gamma));
+    cacc = Fr::mul(cacc, Fr::mul(beta, e[ZE]));
+    cacc = Fr::mul(cacc, alpha);
+    // EvaluationDomain::new(z_poly.degree() - 2) (permutation/proverkey.rs:156)
+    const uint64_t z_eff = poly_.length_without_leading_zeros(p_z, z_len);
+    const uint64_t z_deg = z_eff ? z_eff - 1 : 0;
+    const Domain dz = Domain::make(z_deg >= 2 ? z_deg - 2 : 0);
+    const Fr l1_z = first_lagrange_coefficient(dz, z_ch);
+    term(p_z, z_len, Fr::add(acc, Fr::mul(l1_z, Fr::sqr(alpha))));
+    term(key_poly(S4), n, Fr::neg(cacc));
+    // linearization_poly.rs:211-228
+    const Fr z_n = Fr::pow_u64(z_ch, n), z_2n = Fr::pow_u64(z_ch, 2 * n), z_3n = Fr::pow_u64(z_ch, 3 * n);
+    const Fr zh = Fr::neg(Fr::sub(z_n, Fr::one()));
+    term(t_parts[0], t_lens[0], zh);
+    term(t_parts[1], t_lens[1], Fr::mul(z_n, zh));
+    term(t_parts[2], t_lens[2], Fr::mul(z_2n, zh));
+    term(t_parts[3], t_lens[3], Fr::mul(z_3n, zh));
+    L.n_terms = k;
+    // linearization_poly.rs:187-190 — the reference passes the SPARSE public-input list here
+    L.constant = barycentric_eval(public_inputs, z_ch, domain);
+    if (r_len == 0) r_len = 1;   // the constant term
+    ZK_REQUIRE(r_len <= r_cap, ZKGPU_ERR_DEGREE_LARGE, "PolynomialDegreeTooLarge");
+    L.out = r_out;
+    L.out_len = r_len;
+    poly_.linear_combination(L);
+    return r_len;
+}
+
+// CommitKey::compute_aggregate_witness (kzg10/key.rs:131-146): sum_j v^j p_j, divided by (X - point) with the remainder
+// dropped (Polynomial::ruffini, fft/polynomial.rs:343-357).  `sum_tmp` holds the longest polynomial; returns the
+// witness's coefficient count (one less).
+uint64_t Prover::aggregate_witness(const Fr *const *polys, const uint64_t *lens, int count, const Fr &point, const Fr &v, Fr *sum_tmp,
+                                   Fr *out) {
+    ZK_REQUIRE(count >= 1 && count <= MAX_LIN_TERMS, ZKGPU_ERR_INVALID_ARG, "aggregate_witness: 1 to 18 polynomials");
+    LinArgs L;
+    Fr pw = Fr::one();
+    uint64_t len = 0;
+    for (int k = 0; k < count; k++) {
+        L.t[k].coeffs = polys[k];
+        L.t[k].len = lens[k];
+        L.t[k].scalar = pw;
+        pw = Fr::mul(pw, v);
+        if (lens[k] > len) len = lens[k];
+    }
+    L.n_terms = count;
+    L.constant = Fr::zero();
+    L.out = sum_tmp;
+    L.out_len = len;
+    if (len == 0) return 0;
+    poly_.linear_combination(L);
+    poly_.ruffini(sum_tmp, len, point, out);
+    return len - 1;
+}
+
 int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host, size_t n_pi, const uint64_t *blinders14,
                   ProofOut &out, ProveTimings *timings) {
     ZK_REQUIRE(loaded(), ZKGPU_ERR_NOT_LOADED, "prove: no prover key loaded");
@@ -904,114 +1005,25 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
 
     // protocol phase 5: linearization (linearization_poly.rs:146-272) and openings (prover.rs:439-487)
     const Fr v_ch = tr.challenge_scalar("v_challenge");
-    uint64_t r_len;
-    {
-        typedef InlineMul M;
-        LinArgs L;
-        int k = 0;
-        auto term = [&](const Fr *p, uint64_t len, const Fr &s) {
-            L.t[k].coeffs = p;
-            L.t[k].len = len;
-            L.t[k].scalar = s;
-            k++;
-        };
-        // arithmetic/proverkey.rs:75-107
-        const Fr qa = e[QARITH];
-        term(key_poly(Q_M), n, Fr::mul(Fr::mul(e[A], e[B]), qa));
-        term(key_poly(Q_L), n, Fr::mul(e[A], qa));
-        term(key_poly(Q_R), n, Fr::mul(e[B], qa));
-        term(key_poly(Q_O), n, Fr::mul(e[C], qa));
-        term(key_poly(Q_F), n, Fr::mul(e[D], qa));
-        term(key_poly(Q_C), n, qa);
-        // range / logic / fixed-base / curve-addition compute_linearization
-        term(key_poly(Q_RANGE), n, Fr::mul(w_range_identity<M>(range_ch, e[A], e[B], e[C], e[D], e[DW]), range_ch));
-        term(key_poly(Q_LOGIC), n,
-             Fr::mul(w_logic_identity<M>(logic_ch, e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW], e[QC]), logic_ch));
-        term(key_poly(Q_FIXED), n,
-             Fr::mul(w_fixed_base_identity<M>(fixed_ch, e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW], e[QL], e[QR], e[QC]),
-                     fixed_ch));
-        term(key_poly(Q_VAR), n, Fr::mul(w_curve_add_identity<M>(var_ch, e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW]), var_ch));
-        // permutation/proverkey.rs:121-245
-        const Fr beta_z = Fr::mul(beta, z_ch);
-        Fr acc = Fr::add(Fr::add(e[A], beta_z), gamma);
-        acc = Fr::mul(acc, Fr::add(Fr::add(e[B], mul_small<7>(beta_z)), gamma));
-        acc = Fr::mul(acc, Fr::add(Fr::add(e[C], mul_small<13>(beta_z)), gamma));
-        acc = Fr::mul(acc, Fr::add(Fr::add(e[D], mul_small<17>(beta_z)), gamma));
-        acc = Fr::mul(acc, alpha);
-        Fr cacc = Fr::add(Fr::add(e[A], Fr::mul(beta, e[SG1])), gamma);
-        cacc = Fr::mul(cacc, Fr::add(Fr::add(e[B], Fr::mul(beta, e[SG2])), gamma));
-        cacc = Fr::mul(cacc, Fr::add(Fr::add(e[C], Fr::mul(beta, e[SG3])), gamma));
-        cacc = Fr::mul(cacc, Fr::mul(beta, e[ZE]));
-        cacc = Fr::mul(cacc, alpha);
-        // EvaluationDomain::new(z_poly.degree() - 2) (permutation/proverkey.rs:156)
-        const uint64_t z_eff = poly_.length_without_leading_zeros(p_z, n + 3);
-        const uint64_t z_deg = z_eff ? z_eff - 1 : 0;
-        const Domain dz = Domain::make(z_deg >= 2 ? z_deg - 2 : 0);
-        const Fr l1_z = first_lagrange_coefficient(dz, z_ch);
-        term(p_z, n + 3, Fr::add(acc, Fr::mul(l1_z, Fr::sqr(alpha))));
-        term(key_poly(S4), n, Fr::neg(cacc));
-        // linearization_poly.rs:211-228
-        const Fr z_n = Fr::pow_u64(z_ch, n), z_2n = Fr::pow_u64(z_ch, 2 * n), z_3n = Fr::pow_u64(z_ch, 3 * n);
-        const Fr zh = Fr::neg(Fr::sub(z_n, Fr::one()));
-        term(t_low, n + 1, zh);
-        term(t_mid, n + 1, Fr::mul(z_n, zh));
-        term(t_high, n + 1, Fr::mul(z_2n, zh));
-        term(t_fourth, t4_len, Fr::mul(z_3n, zh));
-        L.n_terms = k;
-        // linearization_poly.rs:187-190 — the reference passes the SPARSE public-input list here
-        L.constant = barycentric_eval(public_inputs, z_ch, domain);
-        r_len = n + 3;
-        if (t4_len > r_len) r_len = t4_len;
-        ZK_REQUIRE(r_len <= lin_cap, ZKGPU_ERR_DEGREE_LARGE, "PolynomialDegreeTooLarge");
-        L.out = r_poly;
-        L.out_len = r_len;
-        poly_.linear_combination(L);
-    }
+    const Fr *t_parts[4] = {t_low, t_mid, t_high, t_fourth};
+    const uint64_t t_lens[4] = {n + 1, n + 1, n + 1, t4_len};
+    const uint64_t r_len = linearization(ch7, z_ch, e, p_z, n + 3, t_parts, t_lens, public_inputs, r_poly, lin_cap);
     lap(5, t_phase);
     // Both opening witnesses are built first and committed together: the prover's transcript does not absorb
     // w_z_chall_comm (prover.rs:439-479), so v_w does not depend on it.  t[0..3n) is free again and holds the second.
-    uint64_t wit_len = 0;
     Fr *wit2 = t;
+    uint64_t wit_len;
     {
         // compute_aggregate_witness (kzg10/key.rs:131-146) at z with powers of v
-        LinArgs L;
         const Fr *ps[8] = {r_poly, p_a, p_b, p_c, p_d, key_poly(S1), key_poly(S2), key_poly(S3)};
         const uint64_t ls[8] = {r_len, n + 2, n + 2, n + 2, n + 2, n, n, n};
-        Fr pw = Fr::one();
-        uint64_t len = 0;
-        for (int k = 0; k < 8; k++) {
-            L.t[k].coeffs = ps[k];
-            L.t[k].len = ls[k];
-            L.t[k].scalar = pw;
-            pw = Fr::mul(pw, v_ch);
-            if (ls[k] > len) len = ls[k];
-        }
-        L.n_terms = 8;
-        L.constant = Fr::zero();
-        L.out = agg;
-        L.out_len = len;
-        poly_.linear_combination(L);
-        poly_.ruffini(agg, len, z_ch, wit);
-        wit_len = len - 1;
+        wit_len = aggregate_witness(ps, ls, 8, z_ch, v_ch, agg, wit);
     }
     const Fr v_w_ch = tr.challenge_scalar("v_w_challenge");
     {
-        LinArgs L;
         const Fr *ps[4] = {p_z, p_a, p_b, p_d};
         const uint64_t ls[4] = {n + 3, n + 2, n + 2, n + 2};
-        Fr pw = Fr::one();
-        for (int k = 0; k < 4; k++) {
-            L.t[k].coeffs = ps[k];
-            L.t[k].len = ls[k];
-            L.t[k].scalar = pw;
-            pw = Fr::mul(pw, v_w_ch);
-        }
-        L.n_terms = 4;
-        L.constant = Fr::zero();
-        L.out = agg;
-        L.out_len = n + 3;
-        poly_.linear_combination(L);
-        poly_.ruffini(agg, n + 3, z_w, wit2);
+        aggregate_witness(ps, ls, 4, z_w, v_w_ch, agg, wit2);
     }
     {
         const Fr *cp[2] = {wit, wit2};

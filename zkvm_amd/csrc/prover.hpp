@@ -72,6 +72,15 @@ class Prover {
     uint64_t quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4], const uint64_t wire_len[4], const Fr *pi,
                       uint64_t pi_len, const Fr challenges7[7], Fr *t_out, const Fr *pi_values = nullptr);
 
+    // build_linearization_polynomial (linearization_poly.rs:146-272) and compute_aggregate_witness
+    // (kzg10/key.rs:131-146) on device polynomials; see prover.hip
+    uint64_t linearization(const Fr ch7[7], const Fr &z_ch, const Fr *evals15, const Fr *p_z, uint64_t z_len,
+                           const Fr *const t_parts[4], const uint64_t t_lens[4], const std::vector<Fr> &public_inputs, Fr *r_out,
+                           uint64_t r_cap);
+    uint64_t aggregate_witness(const Fr *const *polys, const uint64_t *lens, int count, const Fr &point, const Fr &v, Fr *sum_tmp,
+                               Fr *out);
+    PolyEngine &poly() { return poly_; }
+
     // Prover::prove.  wires_host: 4 x n values; blinders: 14 scalars in the reference's draw order.
     // Returns 0 or a ZKGPU_ERR_* code for the reference's error paths.
     int prove(const uint64_t *wires_host, const uint64_t *public_inputs_host, size_t n_pi, const uint64_t *blinders14,

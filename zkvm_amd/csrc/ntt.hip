@@ -15,8 +15,9 @@
 //   * coset_fft  = inputs j < len_in multiplied by g^j while they are loaded (domain.rs:176-185: the powers
 //                  are distributed over the un-padded coefficients), then the forward network.
 // HBM traffic per pass is one read and one write of the vector plus the pass's share of the twiddle table.
-// Inside a pass the tile is held as 9 limbs of 29 bits with lazy reduction (see "tile arithmetic" below); the
-// kernel is bound by integer VALU issue, not by memory.
+// Inside a pass the tile is held as 9 limbs of 29 bits with lazy reduction (see "tile arithmetic" below), two
+// butterfly stages run per LDS round trip (a thread carries four rows in registers), and the tables hold the
+// twiddles in the same limb form, ready to multiply by; the kernel is bound by integer VALU issue, not by memory.
 #include "ntt.hpp"
 
 namespace zk {
@@ -63,10 +64,24 @@ Domain Domain::make(uint64_t num_coeffs) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Entry of a transform's stage table: the twiddle as the nine 29-bit limbs the tile arithmetic multiplies by, so that a
+// butterfly loads its factor ready for use (36 bytes instead of the 32 of the packed form, and no unpacking).
+struct Tw9 {
+    uint32_t v[9];
+};
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void tw_load(const Tw9 *p, uint32_t *w) {
+    const u32x4_unaligned a = *reinterpret_cast<const u32x4_unaligned *>(p->v);
+    const u32x4_unaligned b = *reinterpret_cast<const u32x4_unaligned *>(p->v + 4);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    w[8] = p->v[8];
+}
+
 struct NttPassArgs {
     const Fr *in;
     Fr *out;
-    const Fr *tw;  // stage tables
+    const Tw9 *tw;  // stage tables
     const Fr *gl;  // g^i, i < 4096      (coset_fft input scaling)
     const Fr *gh;  // g^(4096 i)
     uint64_t len_in;
@@ -159,9 +174,40 @@ __device__ __forceinline__ void u9_qreduce(uint32_t *x) {
     x[8] = (uint32_t)(c + (int64_t)x[8] - (int64_t)((uint64_t)q * FrParams::umod(8)));
 }
 
-__global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPassArgs a) {
+__device__ __forceinline__ void ntt_load_bias(uint32_t km, uint32_t *bias) {
+    // literals selected by uniform branches (a table indexed by km would be fetched from memory)
+    if (km == 0) ntt_bias<0>(bias);
+    else if (km == 1) ntt_bias<1>(bias);
+    else if (km == 2) ntt_bias<2>(bias);
+    else ntt_bias<3>(bias);
+}
+// One decimation-in-frequency butterfly on tile limbs: x <- x + y (normalised), y <- (x - y + M r) * w with the
+// stage's bias M r; tw == nullptr stands for w = 1 (the last stage of a plain table).
+__device__ __forceinline__ void u9_butterfly(uint32_t *x, uint32_t *y, const uint32_t *bias, const Tw9 *tw) {
+    uint32_t d[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        d[k] = x[k] + (bias[k] - y[k]);
+        x[k] += y[k];
+    }
+    u9_normalize(x);
+    if (tw) {
+        uint32_t w[9];
+        tw_load(tw, w);
+        Fr::mul_limbs(d, w, y);
+    } else {
+        u9_normalize(d);
+#pragma unroll
+        for (int k = 0; k < 9; k++) y[k] = d[k];
+    }
+}
+
+// LOG_E != 0 fixes the tile at 2^LOG_E elements at compile time, so that the nine limb planes sit at constant LDS
+// offsets; LOG_E == 0 takes any tile geometry (the tuning knob and small transforms).
+template <uint32_t LOG_E, uint32_t MAX_THREADS>
+__global__ void __launch_bounds__(MAX_THREADS) ntt_pass_kernel(NttPassArgs a) {
     extern __shared__ uint32_t lds[];
-    const uint32_t R = 1u << a.log_r, T = 1u << a.log_t, E = R * T;
+    const uint32_t R = 1u << a.log_r, T = 1u << a.log_t, E = LOG_E ? (1u << LOG_E) : R * T;
     const uint32_t tid = threadIdx.x, nt = blockDim.x, tile = blockIdx.x;
     const uint32_t pb = a.log_n - a.log_r - a.b0;  // prefix bits above the row field
 
@@ -213,72 +259,112 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPassArgs a) {
         const uint64_t rows = a.len_in > col0 ? ((a.len_in - col0 - 1) >> a.b0) + 1 : 0;
         live = rows < R ? (uint32_t)rows : R;
     }
+    const uint32_t col_term = a.last ? 0u : col0;   // twiddle index = (row offset << b0) + column
     uint32_t stage = 0;
-    for (uint32_t hj = R >> 1; hj >= 1; hj >>= 1, stage++) {
+    while (stage < a.log_r && live <= (R >> (stage + 1))) {
+        const uint32_t hj = R >> (stage + 1);
         __syncthreads();
         const uint32_t h = hj << a.b0;  // half-size of this stage in the whole network
         const uint32_t lhj = 31 - __clz(hj);
-        const uint32_t km = stage & 3u;
-        const bool sparse = live <= hj;
-        if (sparse) {
-            for (uint32_t bi = tid; bi < (E >> 1); bi += nt) {
-                const uint32_t t = bi & (T - 1);
-                const uint32_t jb = bi >> a.log_t;
-                const uint32_t off = jb & (hj - 1);
-                if (off >= live) continue;
-                const uint32_t j = ((jb >> lhj) << (lhj + 1)) | off;
-                const uint32_t e0 = j * T + t, e1 = e0 + hj * T;
-                uint32_t x[9], y[9];
-                u9_load(lds, E, e0, x);      // normalised and below 2r: it has only been through products so far
-                if (h > 1 || !a.unit_last) {
-                    const uint32_t widx = (off << a.b0) + col0 + t;
-                    uint32_t w[9];
-                    Fr::unpack(gload(a.tw + (h - 1) + widx), w, 0);
-                    Fr::mul_limbs(x, w, y);
-                    u9_store(lds, E, e1, y);
-                } else {
-                    u9_store(lds, E, e1, x);
-                }
+        for (uint32_t bi = tid; bi < (E >> 1); bi += nt) {
+            const uint32_t t = bi & (T - 1);
+            const uint32_t jb = bi >> a.log_t;
+            const uint32_t off = jb & (hj - 1);
+            if (off >= live) continue;
+            const uint32_t j = ((jb >> lhj) << (lhj + 1)) | off;
+            const uint32_t e0 = j * T + t, e1 = e0 + hj * T;
+            uint32_t x[9], y[9];
+            u9_load(lds, E, e0, x);      // normalised and below 2r: it has only been through products so far
+            if (h > 1 || !a.unit_last) {
+                const uint32_t widx = (off << a.b0) + col0 + t;
+                uint32_t w[9];
+                tw_load(a.tw + (h - 1) + widx, w);
+                Fr::mul_limbs(x, w, y);
+                u9_store(lds, E, e1, y);
+            } else {
+                u9_store(lds, E, e1, x);
             }
-            continue;
         }
-        live = hj;   // blocks are full from here on
+        stage++;
+    }
+    // The full stages: one single stage when their number is odd, then two stages per LDS round trip.  A thread
+    // holds the four rows j0 + m * hq (m = 0..3) of one column: the stage with half-size 2 hq pairs (0,2) and (1,3), the
+    // stage with half-size hq pairs (0,1) and (2,3), whose twiddles coincide.  Operand bounds are those of the
+    // stage-by-stage form: inputs of stage k below 2^(k mod 4) * 2r, a quarter-reduction before every fourth stage.
+    if ((a.log_r - stage) & 1u) {
+        const uint32_t hj = R >> (stage + 1);
+        __syncthreads();
+        const uint32_t h = hj << a.b0;
+        const uint32_t lhj = 31 - __clz(hj);
+        const uint32_t km = stage & 3u;
         const bool reduce_in = km == 0 && stage > 0;
-        uint32_t bias[9];   // literals selected by uniform branches (a table indexed by km would be fetched from memory)
-        if (km == 0) ntt_bias<0>(bias);
-        else if (km == 1) ntt_bias<1>(bias);
-        else if (km == 2) ntt_bias<2>(bias);
-        else ntt_bias<3>(bias);
+        const bool has_w = h > 1 || !a.unit_last;
+        uint32_t bias[9];
+        ntt_load_bias(km, bias);
         for (uint32_t bi = tid; bi < (E >> 1); bi += nt) {
             const uint32_t t = bi & (T - 1);
             const uint32_t jb = bi >> a.log_t;
             const uint32_t off = jb & (hj - 1);
             const uint32_t j = ((jb >> lhj) << (lhj + 1)) | off;
             const uint32_t e0 = j * T + t, e1 = e0 + hj * T;
-            uint32_t x[9], y[9], d[9];
+            uint32_t x[9], y[9];
             u9_load(lds, E, e0, x);
             u9_load(lds, E, e1, y);
             if (reduce_in) {
                 u9_qreduce(x);
                 u9_qreduce(y);
             }
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                d[k] = x[k] + (bias[k] - y[k]);
-                x[k] += y[k];
-            }
-            u9_normalize(x);
-            if (h > 1 || !a.unit_last) {
-                const uint32_t widx = (off << a.b0) + (a.last ? 0u : col0 + t);
-                uint32_t w[9];
-                Fr::unpack(gload(a.tw + (h - 1) + widx), w, 0);
-                Fr::mul_limbs(d, w, y);
-                u9_store(lds, E, e1, y);
-            } else {
-                u9_normalize(d);
-                u9_store(lds, E, e1, d);
-            }
+            u9_butterfly(x, y, bias, has_w ? a.tw + (h - 1) + (off << a.b0) + (a.last ? 0u : t) + col_term : nullptr);
+            u9_store(lds, E, e1, y);
             u9_store(lds, E, e0, x);
+        }
+        stage++;
+    }
+    for (; stage + 1 < a.log_r; stage += 2) {
+        const uint32_t hq = R >> (stage + 2);          // the second stage's half-size in rows; the first one's is 2 hq
+        __syncthreads();
+        const uint32_t h_a = (2 * hq) << a.b0, h_b = hq << a.b0;
+        const uint32_t lhq = 31 - __clz(hq);
+        const uint32_t km_a = stage & 3u, km_b = (stage + 1) & 3u;
+        const bool reduce_a = km_a == 0 && stage > 0, reduce_b = km_b == 0;
+        const bool has_w_b = h_b > 1 || !a.unit_last;
+        uint32_t bias_a[9], bias_b[9];
+        ntt_load_bias(km_a, bias_a);
+        ntt_load_bias(km_b, bias_b);
+        for (uint32_t g = tid; g < (E >> 2); g += nt) {
+            const uint32_t t = g & (T - 1);
+            const uint32_t jg = g >> a.log_t;
+            const uint32_t off = jg & (hq - 1);
+            const uint32_t j0 = ((jg >> lhq) << (lhq + 2)) | off;
+            const uint32_t e0 = j0 * T + t, step = hq * T;
+            uint32_t x0[9], x1[9], x2[9], x3[9];
+            u9_load(lds, E, e0, x0);
+            u9_load(lds, E, e0 + step, x1);
+            u9_load(lds, E, e0 + 2 * step, x2);
+            u9_load(lds, E, e0 + 3 * step, x3);
+            if (reduce_a) {
+                u9_qreduce(x0);
+                u9_qreduce(x1);
+                u9_qreduce(x2);
+                u9_qreduce(x3);
+            }
+            const uint32_t col = (a.last ? 0u : t) + col_term;
+            const Tw9 *tw_a = a.tw + (h_a - 1) + (off << a.b0) + col;         // row offsets off and off + hq
+            u9_butterfly(x0, x2, bias_a, tw_a);
+            u9_butterfly(x1, x3, bias_a, tw_a + ((size_t)hq << a.b0));
+            if (reduce_b) {
+                u9_qreduce(x0);
+                u9_qreduce(x1);
+                u9_qreduce(x2);
+                u9_qreduce(x3);
+            }
+            const Tw9 *tw_b = has_w_b ? a.tw + (h_b - 1) + (off << a.b0) + col : nullptr;
+            u9_butterfly(x0, x1, bias_b, tw_b);
+            u9_butterfly(x2, x3, bias_b, tw_b);
+            u9_store(lds, E, e0, x0);
+            u9_store(lds, E, e0 + step, x1);
+            u9_store(lds, E, e0 + 2 * step, x2);
+            u9_store(lds, E, e0 + 3 * step, x3);
         }
     }
     __syncthreads();
@@ -308,7 +394,9 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPassArgs a) {
 }
 
 // out[gid] = c_q * base_q^idx for gid = 2^q - 1 + idx, idx < 2^q ; consts = {base_0, c_0, base_1, c_1, ...}
-__global__ void gen_stage_tables_kernel(Fr *out, uint64_t count, const Fr *consts) {
+// LIMBS: entries in the tile arithmetic's limb form (the transforms' tables); otherwise packed field elements
+template <bool LIMBS>
+__global__ void gen_stage_tables_kernel(void *out, uint64_t count, const Fr *consts) {
     uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= count) return;
     uint32_t q = 63 - __clzll(gid + 1);
@@ -319,7 +407,15 @@ __global__ void gen_stage_tables_kernel(Fr *out, uint64_t count, const Fr *const
         if ((idx >> bit) & 1) r = r * b;
         b = Fr::sqr(b);
     }
-    gstore(out + gid, r);
+    if (LIMBS) {
+        uint32_t u[9];
+        Fr::unpack(r, u, 0);
+        Tw9 *dst = static_cast<Tw9 *>(out) + gid;
+#pragma unroll
+        for (int k = 0; k < 9; k++) dst->v[k] = u[k];
+    } else {
+        gstore(static_cast<Fr *>(out) + gid, r);
+    }
 }
 
 // out[i] = base^i
@@ -366,7 +462,8 @@ size_t NttEngine::device_bytes() const {
            work_.cap + stage_consts_.cap;
 }
 
-static void fill_stage_tables(hipStream_t stream, DevBuf &consts_buf, Fr *table, uint32_t log_n, const Fr &w_n,
+// times_32: a transform's table (limb entries, see Tw9); otherwise the packed table behind roots_half()
+static void fill_stage_tables(hipStream_t stream, DevBuf &consts_buf, void *table, uint32_t log_n, const Fr &w_n,
                               const Fr *coset_base /* g^-1 or null */, bool times_32) {
     // stage q (half-size h = 2^q) uses w_{2h} = w_n^(n/2h) and, for the coset table, c_q = g^(-n/2h)
     std::vector<Fr> consts(2 * 32, Fr::one());
@@ -386,8 +483,12 @@ static void fill_stage_tables(hipStream_t stream, DevBuf &consts_buf, Fr *table,
     ZK_HIP(hipMemcpyAsync(consts_buf.p, consts.data(), consts.size() * sizeof(Fr), hipMemcpyHostToDevice, stream));
     uint64_t count = (1ull << log_n) - 1;
     if (count == 0) return;
-    hipLaunchKernelGGL(gen_stage_tables_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, stream, table, count,
-                       consts_buf.as<Fr>());
+    if (times_32)
+        hipLaunchKernelGGL(gen_stage_tables_kernel<true>, dim3(ceil_div(count, 256)), dim3(256), 0, stream, table, count,
+                           consts_buf.as<Fr>());
+    else
+        hipLaunchKernelGGL(gen_stage_tables_kernel<false>, dim3(ceil_div(count, 256)), dim3(256), 0, stream, table, count,
+                           consts_buf.as<Fr>());
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(stream));  // consts is a host temporary
 }
@@ -395,11 +496,11 @@ static void fill_stage_tables(hipStream_t stream, DevBuf &consts_buf, Fr *table,
 void NttEngine::ensure_tables(uint32_t log_n) {
     if (log_n <= table_log_) return;
     Domain d = Domain::make(1ull << log_n);
-    size_t bytes = ((1ull << log_n)) * sizeof(Fr);
+    size_t bytes = ((1ull << log_n)) * sizeof(Tw9);
     tw_fwd_.reserve(bytes);
     tw_inv_.reserve(bytes);
-    fill_stage_tables(stream_, stage_consts_, tw_fwd_.as<Fr>(), log_n, d.group_gen, nullptr, true);
-    fill_stage_tables(stream_, stage_consts_, tw_inv_.as<Fr>(), log_n, d.group_gen_inv, nullptr, true);
+    fill_stage_tables(stream_, stage_consts_, tw_fwd_.p, log_n, d.group_gen, nullptr, true);
+    fill_stage_tables(stream_, stage_consts_, tw_inv_.p, log_n, d.group_gen_inv, nullptr, true);
     table_log_ = log_n;
 }
 
@@ -408,22 +509,22 @@ const Fr *NttEngine::roots_half(uint32_t log_n) {
     if (plain_log_ != log_n) {
         Domain d = Domain::make(1ull << log_n);
         tw_plain_.reserve(((size_t)1 << log_n) * sizeof(Fr));
-        fill_stage_tables(stream_, stage_consts_, tw_plain_.as<Fr>(), log_n, d.group_gen, nullptr, false);
+        fill_stage_tables(stream_, stage_consts_, tw_plain_.p, log_n, d.group_gen, nullptr, false);
         plain_log_ = log_n;
     }
     // the stage with half-size h = n/2 holds w_n^i at entries h-1 .. 2h-2
     return tw_plain_.as<Fr>() + ((size_t)1 << (log_n - 1)) - 1;
 }
 
-const Fr *NttEngine::coset_inv_table(ShiftTables &st, uint32_t log_n) {
+const void *NttEngine::coset_inv_table(ShiftTables &st, uint32_t log_n) {
     auto it = st.cinv.find(log_n);
-    if (it != st.cinv.end()) return it->second.as<Fr>();
+    if (it != st.cinv.end()) return it->second.p;
     Domain d = Domain::make(1ull << log_n);
     DevBuf &buf = st.cinv[log_n];
-    buf.reserve((1ull << log_n) * sizeof(Fr));
+    buf.reserve((1ull << log_n) * sizeof(Tw9));
     // c_q = (s^-1)^(n/2h): for the top stage (h = n/2) that is s^-1 itself
-    fill_stage_tables(stream_, stage_consts_, buf.as<Fr>(), log_n, d.group_gen_inv, &st.shift_inv, true);
-    return buf.as<Fr>();
+    fill_stage_tables(stream_, stage_consts_, buf.p, log_n, d.group_gen_inv, &st.shift_inv, true);
+    return buf.p;
 }
 
 void NttEngine::ensure_coset_powers(ShiftTables &st, uint32_t log_n) {
@@ -495,12 +596,12 @@ void NttEngine::transform_with(ShiftTables &st, NttMode mode, const Fr *in, size
     ZK_REQUIRE(in != nullptr || len_in == 0, ZKGPU_ERR_INVALID_ARG, "ntt: null input");
     ZK_REQUIRE(out != nullptr, ZKGPU_ERR_INVALID_ARG, "ntt: null output");
     const bool inverse = (mode == NTT_IFFT || mode == NTT_COSET_IFFT);
-    const Fr *tw;
+    const void *tw;
     if (mode == NTT_COSET_IFFT) {
         tw = log_n ? coset_inv_table(st, log_n) : nullptr;
     } else {
         ensure_tables(log_n);
-        tw = inverse ? tw_inv_.as<Fr>() : tw_fwd_.as<Fr>();
+        tw = inverse ? tw_inv_.p : tw_fwd_.p;
     }
     if (mode == NTT_COSET_FFT) ensure_coset_powers(st, log_n);
     if (plan(log_n).count > 1) work_.reserve(((size_t)1 << log_n) * sizeof(Fr));
@@ -513,15 +614,15 @@ void NttEngine::transform_no_alloc(NttMode mode, const Fr *in, size_t len_in, Fr
     ZK_REQUIRE(out != nullptr && work != nullptr, ZKGPU_ERR_INVALID_ARG, "ntt: null output");
     ZK_REQUIRE(tables_resident(mode, log_n), ZKGPU_ERR_NOT_LOADED,
                "ntt: the twiddle tables of this mode and size are not resident; run the allocating transform once first");
-    const Fr *tw;
+    const void *tw;
     if (mode == NTT_COSET_IFFT)
-        tw = log_n ? g_.cinv.find(log_n)->second.as<Fr>() : nullptr;
+        tw = log_n ? g_.cinv.find(log_n)->second.p : nullptr;
     else
-        tw = (mode == NTT_IFFT) ? tw_inv_.as<Fr>() : tw_fwd_.as<Fr>();
+        tw = (mode == NTT_IFFT) ? tw_inv_.p : tw_fwd_.p;
     run_passes(mode, in, len_in, out, log_n, tw, work, g_);
 }
 
-void NttEngine::run_passes(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n, const Fr *tw, Fr *work,
+void NttEngine::run_passes(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n, const void *tw, Fr *work,
                            const ShiftTables &st) {
     const uint64_t n = 1ull << log_n;
     if (len_in > n) len_in = n;  // Vec::resize truncates (domain.rs:146)
@@ -533,7 +634,7 @@ void NttEngine::run_passes(NttMode mode, const Fr *in, size_t len_in, Fr *out, u
         NttPassArgs a;
         a.in = src;
         a.out = last ? out : work;
-        a.tw = tw;
+        a.tw = static_cast<const Tw9 *>(tw);
         a.gl = st.lo.as<Fr>();
         a.gh = st.hi.as<Fr>();
         a.len_in = (i == 0) ? (uint64_t)len_in : n;
@@ -553,11 +654,14 @@ void NttEngine::run_passes(NttMode mode, const Fr *in, size_t len_in, Fr *out, u
         const uint32_t grid = (uint32_t)(n >> tile_log);
         const size_t lds_bytes = E * 9 * sizeof(uint32_t);
         if (!lds_attr_set_) {
-            ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_kernel),
+            ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ntt_pass_kernel<0, 1024>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
             lds_attr_set_ = true;
         }
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3(grid), dim3(threads), lds_bytes, stream_, a);
+        if (tile_log == 9 && threads <= 256)
+            hipLaunchKernelGGL((ntt_pass_kernel<9, 256>), dim3(grid), dim3(threads), lds_bytes, stream_, a);
+        else
+            hipLaunchKernelGGL((ntt_pass_kernel<0, 1024>), dim3(grid), dim3(threads), lds_bytes, stream_, a);
         ZK_HIP(hipGetLastError());
         src = work;
     }

@@ -37,9 +37,10 @@ struct Collective {
     bool usable() const { return fn != nullptr && (world == 2 || world == 4 || world == 8) && rank < world; }
 };
 
-// 2^9-element tiles (16 KiB of LDS, 256 threads): ten workgroups per CU overlap one tile's loads and stores with
-// the butterflies of the others; measured best on MI355X (2^12 tiles leave one workgroup per CU and run 25% slower).
-static const uint32_t NTT_DEFAULT_TILE_LOG = 9, NTT_DEFAULT_EPT_LOG = 1;
+// 2^9-element tiles (18 KiB of LDS, 128 threads, each carrying four elements through two stages): eight workgroups
+// per CU overlap one tile's loads and stores with the butterflies of the others; measured best on MI355X (2^12 tiles
+// leave one workgroup per CU and run 25% slower).
+static const uint32_t NTT_DEFAULT_TILE_LOG = 9, NTT_DEFAULT_EPT_LOG = 2;
 
 class NttEngine {
    public:
@@ -99,12 +100,12 @@ class NttEngine {
         size_t bytes() const;
     };
     void ensure_tables(uint32_t log_n);
-    const Fr *coset_inv_table(ShiftTables &st, uint32_t log_n);
+    const void *coset_inv_table(ShiftTables &st, uint32_t log_n);
     void ensure_coset_powers(ShiftTables &st, uint32_t log_n);
     void set_alt_shift(const Fr &s);
     void transform_with(ShiftTables &st, NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n);
     Plan plan(uint32_t log_n) const;
-    void run_passes(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n, const Fr *tw, Fr *work,
+    void run_passes(NttMode mode, const Fr *in, size_t len_in, Fr *out, uint32_t log_n, const void *tw, Fr *work,
                     const ShiftTables &st);
 
     hipStream_t stream_;

@@ -443,17 +443,17 @@ def tiled_srs(n_points):
 
 
 def quotient_roofline(ctx, n, widgets=False):
-    """quotient_kernel of the most recent proof on `ctx`: one thread per point of the 8n coset."""
+    """quotient_limb_kernel (arithmetic-only circuits) of the most recent proof on `ctx`: one thread per point of the 8n coset."""
     ms = ctx.quotient_kernel_ms()
     streams = 19       # a b c d z | q_m q_l q_r q_o q_f q_c q_arith | sigma 1-4 | X, L1 and PI on the coset
     alg = 8.0 * n * 32 * (streams + 1)
-    products = 24      # 7 arithmetic gate, 16 permutation argument, 1 for 1 / Z_H
+    products = 25      # 7 arithmetic gate, 17 permutation argument (beta X twice: plain and times 32), 1 for 1 / Z_H
     mad_rate = 8.0 * n * products * FR_MADS / 64 / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "quotient_kernel<false> (8n = %d points, %d streams read, 1 written)" % (8 * n, streams),
+    return {"bound": "hbm", "kernel": "quotient_limb_kernel (8n = %d points, %d streams read, 1 written)" % (8 * n, streams),
             "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
             "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(PROFILE_ROUND + "_pmc_prove.csv", "quotient_kernel"),
+            "traffic": pmc_traffic(PROFILE_ROUND + "_pmc_prove.csv", "quotient_limb_kernel"),
             "valu": {"unit": "G v_mad_u64_u32 wave-instructions/s", "achieved": round(mad_rate, 1), "peak": MAD_PEAK_G,
                      "frac": round(mad_rate / MAD_PEAK_G, 3), "field_products_per_point": products}}
 

@@ -122,7 +122,7 @@ def test_bench_one_gpu_line_carries_all_three_metrics():
     assert out["msm"]["value"] > 0 and out["msm"]["unit"] == "Mpts/s" and out["msm"]["ranks_seen"] == 1
     assert out["ntt"]["value"] > 0 and out["ntt"]["unit"] == "GB/s"
     kernels = " ".join(r["kernel"] for r in out["rooflines"])
-    for name in ("ntt_pass_kernel", "quotient_kernel", "bucket reduction"):
+    for name in ("ntt_pass_kernel", "quotient_limb_kernel", "bucket reduction"):
         assert name in kernels
     for r in [out["roofline"]] + out["rooflines"]:
         assert r["avg_launch_ms"] > 0 and 0 < r["frac"] < 1.05, r

@@ -2,6 +2,7 @@
 // exact field operations gives the reference's limbs; the kernels are free to replace the reference's serial
 // recurrences (per-gate inversion + running product, Horner sums, synthetic division) by scans and reductions.
 #include "poly.hpp"
+#include "fr9.cuh"
 #include "widgets.cuh"
 #include <vector>
 
@@ -279,6 +280,101 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs q) {
     st(q.out + i, FM(Fr::add(t, p), q.vh_inv[(q.first + q.world * i) & 7]));
 }
 
+// ---- the same identity on unsaturated limbs, for circuits with the arithmetic and permutation terms only ---------
+// Every operand is unpacked once into nine 29-bit limbs and stays there: sums are plain limb additions without a
+// modular correction, differences add a multiple of r first, and only the one stored result is brought back to
+// canonical form.  A product x * (32 y) / 2^261 = x y / 2^256 keeps the Montgomery scaling when its right operand
+// carries a factor 32: a packed operand gets it for free while it is unpacked (shift 5), a computed one by using
+// (32 beta) and (32 gamma) in place of beta and gamma.  With rho = 2^261 / r = 76.5 a product of values below x r and
+// y r is below (x y / rho + 1) r; the comments give these bounds in units of r.  They stay below 2^261 / r throughout,
+// so every normalised value has its top limb below 2^29 and every column sum of a product fits 64 bits.
+struct L9 {
+    uint32_t v[9];
+};
+static __device__ __forceinline__ L9 l9_mul(L9 x, L9 y) {
+    L9 r;
+    Fr::mul_limbs(x.v, y.v, r.v);
+    return r;
+}
+#define LM(x, y) l9_mul((x), (y))
+__device__ __forceinline__ L9 l9(const Fr &x) {      // the integer x
+    L9 r;
+    Fr::unpack(x, r.v, 0);
+    return r;
+}
+__device__ __forceinline__ L9 l9x32(const Fr &x) {   // the integer 32 x
+    L9 r;
+    Fr::unpack(x, r.v, 5);
+    return r;
+}
+__device__ __forceinline__ L9 l9_sum3(const L9 &x, const L9 &y, const L9 &z) {   // normalised x + y + z
+    L9 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.v[k] = x.v[k] + y.v[k] + z.v[k];
+    u9_normalize(r.v);
+    return r;
+}
+__device__ __forceinline__ L9 l9_small(const L9 &x, uint32_t k) {
+    L9 r;
+    u9_small_mul(x.v, k, r.v);
+    return r;
+}
+
+__global__ void __launch_bounds__(256) quotient_limb_kernel(QuotientArgs q) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.n8) return;
+    const uint32_t iw = (i + q.rot) & (q.n8 - 1);
+    const Fr a = ld(q.a + i), b = ld(q.b + i), c = ld(q.c + i), d = ld(q.d + i);
+    const L9 la = l9(a);
+
+    // arithmetic/proverkey.rs:43-73: (a b q_m + a q_l + b q_r + c q_o + d q_4 + q_c) q_arith + PI
+    L9 t = LM(LM(la, l9x32(b)), l9x32(ld(q.sel[Q_M] + i)));         // each product below 1.42
+    u9_add(t.v, LM(la, l9x32(ld(q.sel[Q_L] + i))).v);
+    u9_add(t.v, LM(l9(b), l9x32(ld(q.sel[Q_R] + i))).v);
+    u9_add(t.v, LM(l9(c), l9x32(ld(q.sel[Q_O] + i))).v);
+    u9_add(t.v, LM(l9(d), l9x32(ld(q.sel[Q_F] + i))).v);
+    u9_add(t.v, l9(ld(q.sel[Q_C] + i)).v);                          // below 5 * 1.42 + 1 = 8.1
+    u9_normalize(t.v);
+    t = LM(t, l9x32(ld(q.sel[Q_ARITH] + i)));                       // below 4.4
+    u9_add(t.v, l9(ld(q.pi + i)).v);                                // below 5.4, limbs below 2^30
+
+    // permutation/proverkey.rs:39-119
+    const L9 beta32 = l9x32(q.beta), beta_x32 = l9x32(q.beta_x32);
+    const L9 gamma = l9(q.gamma), gamma_x32 = l9(q.gamma_x32);
+    const L9 lx = l9(ld(q.linear + i));
+    const L9 bx = LM(lx, beta32);                                   // beta X, below 1.42
+    const L9 bx32 = LM(lx, beta_x32);                               // 32 beta X mod r, below 1.42
+    L9 id = l9_sum3(la, bx, gamma);                                 // below 3.42
+    id = LM(id, l9_sum3(l9x32(b), l9_small(bx32, 7), gamma_x32));   // factor below 32 + 10 + 1 -> 2.93
+    id = LM(id, l9_sum3(l9x32(c), l9_small(bx32, 13), gamma_x32));  // factor below 51.5 -> 2.98
+    id = LM(id, l9_sum3(l9x32(d), l9_small(bx32, 17), gamma_x32));  // factor below 57.2 -> 3.23
+    id = LM(id, l9x32(ld(q.z + i)));                                // below 2.36
+    L9 cp = l9_sum3(la, LM(l9(ld(q.sel[S1] + i)), beta32), gamma);  // below 3.42
+    cp = LM(cp, l9_sum3(l9x32(b), LM(l9(ld(q.sel[S2] + i)), beta_x32), gamma_x32));   // factor below 34.5 -> 2.55
+    cp = LM(cp, l9_sum3(l9x32(c), LM(l9(ld(q.sel[S3] + i)), beta_x32), gamma_x32));   // 2.15
+    cp = LM(cp, l9_sum3(l9x32(d), LM(l9(ld(q.sel[S4] + i)), beta_x32), gamma_x32));   // 1.97
+    cp = LM(cp, l9x32(ld(q.z + iw)));                               // below 1.83
+    uint32_t bias[9];
+    ntt_bias<0>(bias);                                              // 4 r, every limb at least that of a value below 2r
+    L9 df;
+#pragma unroll
+    for (int k = 0; k < 9; k++) df.v[k] = id.v[k] + (bias[k] - cp.v[k]);   // id - cp + 4r: below 6.4, limbs below 2^31
+    u9_add(t.v, LM(df, l9x32(q.alpha)).v);                          // + below 3.7
+    // (z - 1) L1 alpha^2
+    const L9 one = l9(Fr::one());
+    L9 zm = l9(ld(q.z + i));
+#pragma unroll
+    for (int k = 0; k < 9; k++) zm.v[k] += bias[k] - one.v[k];      // z - 1 + 4r: below 5
+    u9_add(t.v, LM(LM(zm, l9x32(ld(q.l1 + i))), l9x32(q.alpha_sq)).v);     // 3.1 -> + below 2.3: t below 11.4
+    u9_normalize(t.v);
+
+    // quotient_poly.rs:88-95: numerator / Z_H
+    t = LM(t, l9x32(q.vh_inv[(q.first + q.world * i) & 7]));        // below 5.8
+    u9_qreduce(t.v);
+    Fr::cond_sub_limbs(t.v);
+    st(q.out + i, Fr::pack(t.v));
+}
+
 void PolyEngine::quotient(const QuotientArgs &args) {
     ZK_REQUIRE(args.n8 >= args.rot && (args.n8 & (args.n8 - 1)) == 0, ZKGPU_ERR_INVALID_ARG, "quotient: 8n must be a power of two");
     ZK_REQUIRE(args.world >= 1 && args.world * args.rot == 8 && args.first < args.world, ZKGPU_ERR_INVALID_ARG,
@@ -288,10 +384,14 @@ void PolyEngine::quotient(const QuotientArgs &args) {
         ZK_HIP(hipEventCreate(&q_ev_[1]));
     }
     ZK_HIP(hipEventRecord(q_ev_[0], stream_));
-    if (args.widgets)
+    if (args.widgets) {
         hipLaunchKernelGGL(quotient_kernel<true>, dim3(ceil_div(args.n8, 256)), dim3(256), 0, stream_, args);
-    else
-        hipLaunchKernelGGL(quotient_kernel<false>, dim3(ceil_div(args.n8, 256)), dim3(256), 0, stream_, args);
+    } else {
+        QuotientArgs q = args;
+        q.beta_x32 = mul_small<32>(args.beta);
+        q.gamma_x32 = mul_small<32>(args.gamma);
+        hipLaunchKernelGGL(quotient_limb_kernel, dim3(ceil_div(args.n8, 256)), dim3(256), 0, stream_, q);
+    }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipEventRecord(q_ev_[1], stream_));
     q_recorded_ = true;

@@ -18,6 +18,7 @@ struct QuotientArgs {
     Fr *out;                           // numerator / Z_H
     Fr alpha, alpha_sq, beta, gamma, range_ch, logic_ch, fixed_ch, var_ch;
     Fr vh_inv[8];                      // 1 / Z_H on the coset has period 8
+    Fr beta_x32, gamma_x32;            // 32 beta, 32 gamma: filled in by PolyEngine::quotient
     uint32_t n8;                       // 8n, or the 8n / world points this GPU owns when the coset is dealt out
     // With the 8n points shared by `world` GPUs, this GPU owns the points i = first + world * k, k < n8 (world divides
     // 8): the "next row" i + 8 is the local k + rot with rot = 8 / world, and Z_H's period-8 table is read at

@@ -29,6 +29,27 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == names
 
 
+def test_rccl_library_exports_every_declared_symbol():
+    """libzkgpu_rccl.so, the optional RCCL implementation of the exchange callbacks (include/zkgpu_rccl.h)."""
+    import ctypes
+    path = os.path.join(ROOT, "zkvm_amd", "libzkgpu_rccl.so")
+    assert os.path.exists(path), "build libzkgpu_rccl.so first (__graft_entry__.build())"
+    text = open(os.path.join(ROOT, "include", "zkgpu_rccl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(zkgpu_rccl_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) == 7
+    lib = ctypes.CDLL(path)
+    for name in names:
+        assert hasattr(lib, name), name
+    # without a GPU the identifier cannot be created: the call must return an error, not crash
+    import torch
+    if not torch.cuda.is_available():
+        buf = (ctypes.c_uint8 * 128)()
+        lib.zkgpu_rccl_init.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        out = ctypes.c_void_p()
+        assert lib.zkgpu_rccl_init(ctypes.byref(out), buf, 3, 2, 0) != 0   # rank outside the world
+
+
 def test_init_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

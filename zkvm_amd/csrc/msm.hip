@@ -797,6 +797,7 @@ MsmEngine::~MsmEngine() {
     DevBuf *all[] = {&points_, &counts_, &offsets_, &cursor_, &sorted_, &buckets_, &block_sums_, &tasks_, &partials_,
                      &misc_,   &seg_,    &group_sums_, &order_, &digits_, &table28_, &range_cnt_, &mid_};
     for (DevBuf *b : all) b->release();
+    if (host_sums_) (void)hipHostFree(host_sums_);
 }
 
 size_t MsmEngine::device_bytes() const {
@@ -1222,12 +1223,23 @@ void MsmEngine::msm_device(const Fr *scalars_dev, size_t n, size_t base, uint32_
     msm_batch_device(1, &scalars_dev, &n, base, n_groups, log_seg_out);
 }
 
-void MsmEngine::finish_batch(uint32_t m, uint32_t groups, uint32_t log_seg, G1Proj *out) {
-    std::vector<G1Proj> all((size_t)m * groups);
-    ZK_HIP(hipMemcpyAsync(all.data(), group_sums_.p, all.size() * sizeof(G1Proj), hipMemcpyDeviceToHost, stream_));
-    ZK_HIP(hipStreamSynchronize(stream_));
+void MsmEngine::ensure_pinned() {
+    if (!host_sums_) ZK_HIP(hipHostMalloc(&host_sums_, 64 + (size_t)MAX_BATCH * MAX_GROUPS * sizeof(G1Proj), hipHostMallocDefault));
+}
+void *MsmEngine::pinned_scratch() {
+    ensure_pinned();
+    return host_sums_;
+}
+void MsmEngine::enqueue_result_copy(uint32_t m, uint32_t groups) {
+    ZK_REQUIRE(m <= MAX_BATCH && groups <= MAX_GROUPS, ZKGPU_ERR_INTERNAL, "msm: group sums beyond the pinned buffer");
+    ensure_pinned();
+    ZK_HIP(hipMemcpyAsync(static_cast<char *>(host_sums_) + 64, group_sums_.p, (size_t)m * groups * sizeof(G1Proj),
+                          hipMemcpyDeviceToHost, stream_));
+}
+void MsmEngine::finish_host(uint32_t m, uint32_t groups, uint32_t log_seg, G1Proj *out) {
+    const G1Proj *all = reinterpret_cast<const G1Proj *>(static_cast<const char *>(host_sums_) + 64);
     for (uint32_t j = 0; j < m; j++) {
-        const G1Proj *gs = all.data() + (size_t)j * groups;
+        const G1Proj *gs = all + (size_t)j * groups;
         // sum_b (b+1) bucket_b = sum_s W_s + L * sum_k 2^k Q_k + sum_s T_s (group layout: msm_group_partial_kernel)
         if (groups == 2) {
             out[j] = g1_add(gs[0], gs[1]);
@@ -1244,6 +1256,11 @@ void MsmEngine::finish_batch(uint32_t m, uint32_t groups, uint32_t log_seg, G1Pr
         total = g1_add(total, g1_add(gs[n_bits + 1], gs[n_bits + 2]));
         out[j] = total;
     }
+}
+void MsmEngine::finish_batch(uint32_t m, uint32_t groups, uint32_t log_seg, G1Proj *out) {
+    enqueue_result_copy(m, groups);
+    ZK_HIP(hipStreamSynchronize(stream_));
+    finish_host(m, groups, log_seg, out);
 }
 
 G1Proj MsmEngine::finish(uint32_t groups, uint32_t log_seg) {

@@ -46,6 +46,13 @@ class MsmEngine {
     void msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const size_t *lens, size_t base, uint32_t &n_groups,
                           uint32_t &log_seg);
     void finish_batch(uint32_t m, uint32_t n_groups, uint32_t log_seg, G1Proj *out);
+    // finish_batch in two steps, for a caller that has other device work to launch while the host adds the group
+    // sums: enqueue_result_copy() puts the copy of the m * n_groups group sums into pinned host memory on the stream;
+    // once the stream (or an event recorded behind the copy) has been waited for, finish_host() combines them.
+    void enqueue_result_copy(uint32_t m, uint32_t n_groups);
+    void finish_host(uint32_t m, uint32_t n_groups, uint32_t log_seg, G1Proj *out);
+    // 64 bytes of pinned host memory for a caller's own small read-back that rides on the same wait
+    void *pinned_scratch();
 
     // Five HIP events recorded on the stream at the phase boundaries of the next device phases: start, before and
     // after msm_accumulate_kernel, before the reduction, end.  nullptr switches the recording off.
@@ -77,6 +84,9 @@ class MsmEngine {
     uint32_t window_override_ = 0;
     hipEvent_t *profile_ = nullptr;
     bool lds_attr_set_ = false;
+    void *host_sums_ = nullptr;   // pinned: 64 scratch bytes, then MAX_BATCH * MAX_GROUPS group sums
+    static const uint32_t MAX_GROUPS = 40;
+    void ensure_pinned();
 };
 
 }  // namespace zk

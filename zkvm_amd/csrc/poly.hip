@@ -632,7 +632,7 @@ __global__ void __launch_bounds__(1024) degree_kernel(const Fr *coeffs, uint64_t
         if (mine > *reinterpret_cast<volatile unsigned long long *>(out)) atomicMax(out, mine);
     }
 }
-void PolyEngine::lengths_without_leading_zeros(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, uint64_t *out) {
+void PolyEngine::lengths_enqueue(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, unsigned long long *host_out) {
     ZK_REQUIRE(m <= 8, ZKGPU_ERR_INVALID_ARG, "lengths_without_leading_zeros: at most 8 vectors");
     jobs_.reserve(64);
     unsigned long long *d = jobs_.as<unsigned long long>();
@@ -641,8 +641,11 @@ void PolyEngine::lengths_without_leading_zeros(uint32_t m, const Fr *const *coef
         if (lens[j])
             hipLaunchKernelGGL(degree_kernel, dim3(ceil_div(lens[j], 4096)), dim3(1024), 0, stream_, coeffs[j], lens[j], d + j);
     ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(host_out, d, 8 * m, hipMemcpyDeviceToHost, stream_));
+}
+void PolyEngine::lengths_without_leading_zeros(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, uint64_t *out) {
     unsigned long long h[8];
-    ZK_HIP(hipMemcpyAsync(h, d, 8 * m, hipMemcpyDeviceToHost, stream_));
+    lengths_enqueue(m, coeffs, lens, h);
     ZK_HIP(hipStreamSynchronize(stream_));
     for (uint32_t j = 0; j < m; j++) out[j] = (uint64_t)h[j];
 }

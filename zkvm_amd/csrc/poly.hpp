@@ -82,6 +82,9 @@ class PolyEngine {
     uint64_t length_without_leading_zeros(const Fr *coeffs, uint64_t len);
     // the same for up to 8 vectors with a single synchronisation
     void lengths_without_leading_zeros(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, uint64_t *out);
+    // the same without the wait: the m lengths arrive in host_out (pinned host memory, 8 bytes each) once the stream
+    // has run past this call
+    void lengths_enqueue(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, unsigned long long *host_out);
 
     size_t device_bytes() const { return s0_.cap + s1_.cap + s2_.cap + s3_.cap + jobs_.cap; }
 

@@ -83,6 +83,7 @@ Prover::~Prover() {
     work_.release();
     small_.release();
     pi_lagrange_.release();
+    if (sums_ready_) (void)hipEventDestroy(sums_ready_);
 }
 
 size_t Prover::device_bytes() const {
@@ -113,15 +114,13 @@ int Prover::commit_dev(const Fr *coeffs, uint64_t len, AffineOut &out) { return 
 // With sharding set, this context holds the points [shard_base_, shard_base_ + n_local) of an SRS of total_points_
 // points: it sums its own range of every polynomial, the partial sums of all ranks are exchanged through the
 // caller's function and added in rank order, so every rank obtains the same commitments.
-int Prover::commit_many(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, AffineOut *out) {
-    uint64_t eff[MsmEngine::MAX_BATCH];
-    poly_.lengths_without_leading_zeros(m, coeffs, lens, eff);
+int Prover::commit_many(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, AffineOut *out,
+                        const std::function<void()> &meanwhile) {
+    // The lengths without leading zeros decide the reference's degree errors; they are read back together with the
+    // sums, which are taken over the given lengths meanwhile (zero coefficients add nothing to a sum).
+    unsigned long long *eff = static_cast<unsigned long long *>(msm_.pinned_scratch());
+    poly_.lengths_enqueue(m, coeffs, lens, eff);
     const uint64_t total_points = exchange_ ? total_points_ : msm_.n_points();
-    for (uint32_t j = 0; j < m; j++) {
-        const uint64_t degree = eff[j] ? eff[j] - 1 : 0;
-        if (degree == 0) return ZKGPU_ERR_DEGREE_ZERO;
-        if (degree > total_points - 1) return ZKGPU_ERR_DEGREE_LARGE;
-    }
     // this context's share of every sum
     const uint64_t lo = exchange_ ? shard_base_ : 0, local_points = msm_.n_points();
     const Fr *ptr[MsmEngine::MAX_BATCH];
@@ -130,15 +129,29 @@ int Prover::commit_many(uint32_t m, const Fr *const *coeffs, const uint64_t *len
     G1Proj sums[MsmEngine::MAX_BATCH];
     for (uint32_t j = 0; j < m; j++) {
         sums[j] = G1Proj::identity();
-        uint64_t hi = eff[j] < lo + local_points ? eff[j] : lo + local_points;
+        uint64_t hi = lens[j] < lo + local_points ? lens[j] : lo + local_points;
         if (hi <= lo) continue;
         ptr[k] = coeffs[j] + lo;
         cnt[k] = (size_t)(hi - lo);
         slot[k++] = j;
     }
+    uint32_t groups = 0, log_seg = 0;
+    if (k) {
+        msm_.msm_batch_device(k, ptr, cnt, 0, groups, log_seg);
+        msm_.enqueue_result_copy(k, groups);
+    }
+    if (!sums_ready_) ZK_HIP(hipEventCreateWithFlags(&sums_ready_, hipEventDisableTiming));
+    ZK_HIP(hipEventRecord(sums_ready_, stream_));
+    if (meanwhile) meanwhile();
+    ZK_HIP(hipEventSynchronize(sums_ready_));
+    for (uint32_t j = 0; j < m; j++) {
+        const uint64_t degree = eff[j] ? eff[j] - 1 : 0;
+        if (degree == 0) return ZKGPU_ERR_DEGREE_ZERO;
+        if (degree > total_points - 1) return ZKGPU_ERR_DEGREE_LARGE;
+    }
     if (k) {
         G1Proj part[MsmEngine::MAX_BATCH];
-        msm_.msm_batch(k, ptr, cnt, 0, part);
+        msm_.finish_host(k, groups, log_seg, part);
         for (uint32_t i = 0; i < k; i++) sums[slot[i]] = part[i];
     }
     if (exchange_) {
@@ -620,12 +633,16 @@ uint64_t Prover::quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4],
     const size_t N8 = (size_t)8 * n_, L = ev_len_;   // L = the coset points this context evaluates
     ZK_REQUIRE(!shared() || (coll_.usable() && coll_.world == key_world_ && coll_.rank == key_rank_), ZKGPU_ERR_INVALID_ARG,
                "quotient: the key was loaded for another set of ranks than set_collective names now");
-    small_.reserve((6 + (shared() ? 1 : 0)) * L * sizeof(Fr));
+    small_.reserve(coset_buffer_bytes());
     Fr *ev = small_.as<Fr>();
     const uint32_t lg8 = log_n_ + 3;
-    // quotient_poly.rs:46-51,120
-    coset_fft_8n(z, z_len, ev);
-    for (int k = 0; k < 4; k++) coset_fft_8n(wires[k], wire_len[k], ev + (size_t)(k + 1) * L);
+    // quotient_poly.rs:46-51,120; prove() may have launched some of these transforms already, while it waited for a
+    // commitment
+    const uint32_t ready = ev_ready_;
+    ev_ready_ = 0;
+    if (!(ready & 1u)) coset_fft_8n(z, z_len, ev);
+    if (!(ready & 2u))
+        for (int k = 0; k < 4; k++) coset_fft_8n(wires[k], wire_len[k], ev + (size_t)(k + 1) * L);
     if (pi != nullptr) {
         coset_fft_8n(pi, pi_len, ev + 5 * L);
     } else {
@@ -860,10 +877,23 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     Fr *wp[4] = {p_a, p_b, p_c, p_d};
     for (int k = 0; k < 4; k++) blind_poly(wires + k * n, 1, bl + 2 * k, wp[k]);
     int rc;
+    // The coset evaluations the quotient needs of a polynomial depend on no challenge: they are launched right behind
+    // the polynomial's commitment and run while the host adds up the commitment and feeds the transcript.
+    ev_ready_ = 0;
+    struct ClearOnExit {
+        uint32_t &flags;
+        ~ClearOnExit() { flags = 0; }   // an error return must not leave the marks for a later quotient() call
+    } clear_ready{ev_ready_};
+    small_.reserve(coset_buffer_bytes());
+    Fr *const coset_ev = small_.as<Fr>();
     {
         const Fr *cp[4] = {p_a, p_b, p_c, p_d};
         const uint64_t cl[4] = {n + 2, n + 2, n + 2, n + 2};
-        if ((rc = commit_many(4, cp, cl, &out.comms[0]))) return rc;
+        rc = commit_many(4, cp, cl, &out.comms[0], [&] {
+            for (int k = 0; k < 4; k++) coset_fft_8n(wp[k], n + 2, coset_ev + (size_t)(k + 1) * ev_len_);
+            ev_ready_ |= 2u;
+        });
+        if (rc) return rc;
     }
     tr.append_commitment("a_comm", out.comms[0]);
     tr.append_commitment("b_comm", out.comms[1]);
@@ -881,7 +911,15 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
         poly_.permutation_z(wv, sv, beta, gamma, ntt_.roots_half(log_n_), (uint32_t)n, z_evals);
     }
     blind_poly(z_evals, 2, bl + 8, p_z);
-    if ((rc = commit_dev(p_z, n + 3, out.comms[4]))) return rc;
+    {
+        const Fr *cp[1] = {p_z};
+        const uint64_t cl[1] = {n + 3};
+        rc = commit_many(1, cp, cl, &out.comms[4], [&] {
+            coset_fft_8n(p_z, n + 3, coset_ev);
+            ev_ready_ |= 1u;
+        });
+        if (rc) return rc;
+    }
     tr.append_commitment("z_comm", out.comms[4]);
     lap(1, t_phase);
 

@@ -9,6 +9,7 @@
 #include "ntt.hpp"
 #include "poly.hpp"
 #include "transcript.hpp"
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -91,7 +92,10 @@ class Prover {
    private:
     // CommitKey::commit (kzg10/key.rs:108-129) of a device polynomial
     int commit_dev(const Fr *coeffs, uint64_t len, AffineOut &out);
-    int commit_many(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, AffineOut *out);
+    // `meanwhile`, when given, is called once the sums are on the stream: device work it launches runs while the host
+    // waits for the sums and finishes them
+    int commit_many(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, AffineOut *out,
+                    const std::function<void()> &meanwhile = nullptr);
     void blind_poly(const Fr *evals_dev, int hiding_degree, const Fr *blinders, Fr *out_dev);
     void build_l1_and_vanishing(bool with_linear);
     void build_pi_lagrange();
@@ -99,6 +103,8 @@ class Prover {
     // context's cyclic slice of them when the key was loaded under set_collective
     void coset_fft_8n(const Fr *coeffs, uint64_t len, Fr *out);
     bool shared() const { return key_world_ > 1; }
+    // z, the four wires and the public inputs on this context's coset points, plus the quotient's slice when shared
+    size_t coset_buffer_bytes() const { return (6 + (shared() ? 1 : 0)) * ev_len_ * sizeof(Fr); }
 
     hipStream_t stream_;
     NttEngine &ntt_;
@@ -126,6 +132,9 @@ class Prover {
     DevBuf sigma_;   // 4 x n sigma values (their FFT is what compute_permutation_vec recomputes)
     DevBuf work_;    // per-proof buffers
     DevBuf small_;   // 15 evaluations etc.
+    hipEvent_t sums_ready_ = nullptr;   // behind the copy of a commitment's group sums
+    // coset evaluations prove() has already launched into small_ for the coming quotient(): bit 0 z, bit 1 the wires
+    uint32_t ev_ready_ = 0;
     DevBuf pi_lagrange_;                  // for keys with few public inputs: L_j on the 8n coset, one vector per position
     std::vector<uint64_t> pi_lagrange_idx_;   // the distinct positions, ascending; empty = not resident
 };

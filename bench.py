@@ -506,6 +506,8 @@ def run_prove(args, rank, world, local, device):
     if rank == 0:
         assert np.array_equal(timed["comms"], proof["comms"]) and np.array_equal(timed["evals"], proof["evals"])
         out["phase_ms"] = {k: round(v, 3) for k, v in timed["timings_ms"].items()}
+        out["phase_note"] = ("laps between the transcript's waits: the coset transforms of the wires and of z run behind their "
+                             "commitments and count into the first two laps")
         out["setup_s"] = {"srs_gpu": round(t_srs, 3), "circuit_host": round(t_circ, 2), "key_preprocess_gpu": round(t_key, 3)}
         out["proof_digest"] = {"a_comm_x0": hex(int(proof["comms"][0][0])), "z_eval_0": hex(int(proof["evals"][14][0]))}
         quot = quotient_roofline(ctx, n)

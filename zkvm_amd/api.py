@@ -348,6 +348,9 @@ COMMITMENT_NAMES = ["a_comm", "b_comm", "c_comm", "d_comm", "z_comm", "t_low_com
                     "t_fourth_comm", "w_z_chall_comm", "w_z_chall_w_comm"]
 EVALUATION_NAMES = ["a_eval", "b_eval", "c_eval", "d_eval", "a_w_eval", "b_w_eval", "d_w_eval", "q_arith_eval", "q_c_eval",
                     "q_l_eval", "q_r_eval", "s_sigma_1_eval", "s_sigma_2_eval", "s_sigma_3_eval", "z_eval"]
+# Wall-clock laps of one prove() at the points where the transcript needs the device.  The coset transforms of the
+# wires and of z are launched behind their commitments, so their time falls into the first two laps, and "quotient" is
+# the public-input term, the quotient kernel and the inverse coset transform.
 PHASE_NAMES = ["wire_commits", "permutation", "quotient", "quotient_commits", "evaluations", "linearization", "openings",
                "total"]
 

@@ -226,7 +226,8 @@ def ntt_roofline(ctx, coeffs, buf_8n):
                      "frac": round(mad_rate / MAD_PEAK_G, 3), "mads_per_butterfly": FR_MADS,
                      "busy_frac_pmc": pmc_valu_busy(PROFILE_ROUND + "_pmc_ntt.csv", "ntt_pass_kernel")},
             "note": "integer-VALU-bound, not memory-bound: one Fr product (%d multiply-accumulates) plus an add, a subtract, "
-                    "the twiddle unpack and 36 LDS accesses per butterfly" % FR_MADS}
+                    "two carry sweeps and 18 LDS accesses per butterfly (two stages per LDS round trip, twiddles kept in limb form)"
+                    % FR_MADS}
 
 
 def measure_ntt(ctx, rank, world, device, steps, warmup):

@@ -358,13 +358,22 @@ def msm_rooflines(ctx, scalars, shard):
     if sort_ms > 0:
         # count pass reads the keys (4 B per pair), scatter pass reads keys and table indices (8 B) and writes 4 B
         sort_bytes = items * 16.0
-        sort_kernel = "msm_sort2_kernel" if window > 16 else "msm_sort_kernel"      # two-level sort above 2^15 buckets
-        others.append({"bound": "hbm", "kernel": "%s<0> + <1> (count and scatter pass over %d pairs)" % (sort_kernel, items),
+        if window > 16:      # two-level sort above 2^15 buckets: count pass, then the LDS-staged final pass
+            sort_name, pmc_names = "msm_sort2_kernel<0> + msm_sort3_kernel", ("msm_sort2_kernel", "msm_sort3_kernel")
+            note = ("the final pass orders a tile of 2^14 entries by bucket in LDS and stores contiguous runs: bound by HBM and "
+                    "LDS traffic, no longer by the transaction rate of lane-scattered 4-byte stores")
+        else:
+            sort_name, pmc_names = "msm_sort_kernel<0> + <1>", ("msm_sort_kernel",)
+            note = "one-level LDS counting sort; scattered 4-byte stores"
+        traffic = None
+        if shard & (shard - 1) == 0:
+            parts = [pmc_traffic(pmc_file, k) for k in pmc_names]
+            traffic = sum(parts) if all(p is not None for p in parts) else None
+        others.append({"bound": "hbm", "kernel": "%s (count and placing pass over %d pairs)" % (sort_name, items),
                        "avg_launch_ms": round(sort_ms / 2, 4), "algorithmic_bytes_per_launch": int(sort_bytes / 2),
                        "achieved": round(sort_bytes / (sort_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(sort_bytes / (sort_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                       "traffic": pmc_traffic(pmc_file, sort_kernel) if shard & (shard - 1) == 0 else None,
-                       "note": "scattered 4-byte stores: bound by L2 write combining, not by HBM bandwidth"})
+                       "traffic": traffic, "note": note})
     buckets = 1 << (window - 1)
     red_adds = 2.0 * buckets                    # running sums: two accumulator additions per bucket, then the trees
     red_rate = red_adds * 12 * FQ28_MADS / 64 / (ph["reduce"] * 1e-3) / 1e9

@@ -242,27 +242,27 @@ __global__ void __launch_bounds__(1024) msm_sort_kernel(SumArgs a, uint32_t firs
 // With B > 2^15 buckets the one-level sort above makes every bucket range scan the whole digit list.  Here the
 // items are first partitioned by bucket range (a counting sort with n_ranges bins, items of one workgroup counted
 // and placed with LDS atomics), then every range sorts only its own items with the LDS histogram.
-static const uint32_t RANGE_ITEMS = 4096;   // items per workgroup in the range partition
+static const uint32_t RANGE_PER_THREAD = 16;   // items per thread in the range partition
 static const uint32_t MAX_RANGES = 1024;
 // pass 0: blockcnt[r * n_blocks + blk] = items of block blk in range r;  pass 1: place them
 //   mid_key = bucket index inside the range | sign << 31,  mid_val = table index w * stride + base + i
-template <int PASS>
-__global__ void __launch_bounds__(256) msm_range_kernel(const uint32_t *dig, SortGeom g, uint32_t n_ranges, uint32_t n_blocks,
-                                                        uint32_t *blockcnt, uint32_t *mid_key, uint32_t *mid_val) {
+template <int PASS, uint32_t THREADS>
+__global__ void __launch_bounds__(THREADS) msm_range_kernel(const uint32_t *dig, SortGeom g, uint32_t n_ranges, uint32_t n_blocks,
+                                                            uint32_t *blockcnt, uint32_t *mid_key, uint32_t *mid_val) {
     __shared__ uint32_t bins[MAX_RANGES];
     const uint32_t blk = blockIdx.x;
-    for (uint32_t t = threadIdx.x; t < n_ranges; t += 256) bins[t] = PASS ? blockcnt[(size_t)t * n_blocks + blk] : 0u;
+    for (uint32_t t = threadIdx.x; t < n_ranges; t += THREADS) bins[t] = PASS ? blockcnt[(size_t)t * n_blocks + blk] : 0u;
     __syncthreads();
-    const uint32_t lo = blk * RANGE_ITEMS;
-    uint32_t vv[RANGE_ITEMS / 256];
+    const uint32_t lo = blk * (RANGE_PER_THREAD * THREADS);
+    uint32_t vv[RANGE_PER_THREAD];
 #pragma unroll
-    for (uint32_t u = 0; u < RANGE_ITEMS / 256; u++) {
-        const uint32_t j = lo + u * 256 + threadIdx.x;
+    for (uint32_t u = 0; u < RANGE_PER_THREAD; u++) {
+        const uint32_t j = lo + u * THREADS + threadIdx.x;
         vv[u] = j < g.n_items ? dig[j] : 0u;
     }
 #pragma unroll
-    for (uint32_t u = 0; u < RANGE_ITEMS / 256; u++) {
-        const uint32_t j = lo + u * 256 + threadIdx.x, v = vv[u];
+    for (uint32_t u = 0; u < RANGE_PER_THREAD; u++) {
+        const uint32_t j = lo + u * THREADS + threadIdx.x, v = vv[u];
         const uint32_t mag = v & 0x7fffffffu;
         if (!mag) continue;
         const uint32_t b = mag - 1, r = b >> g.log_range;
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256) msm_range_kernel(const uint32_t *dig, Sor
     }
     if (!PASS) {
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < n_ranges; t += 256) blockcnt[(size_t)t * n_blocks + blk] = bins[t];
+        for (uint32_t t = threadIdx.x; t < n_ranges; t += THREADS) blockcnt[(size_t)t * n_blocks + blk] = bins[t];
     }
 }
 // adds the scanned block sums: offsets[i] += block_sums[i / SCAN_ITEMS]
@@ -303,6 +303,152 @@ __device__ __forceinline__ void sort2_block(uint32_t lin, uint32_t S, uint32_t n
         s = q * per + x / n_ranges;
     }
 }
+// ---- staged variants: stores leave the workgroup as contiguous runs ---------------------------------------------
+// A lane-scattered 4-byte store costs one memory transaction per lane whatever the L2 later makes of it, and that
+// transaction rate, not bandwidth, bounds the two placing passes above.  Here a workgroup first orders its 2^14
+// items by destination in LDS (rank by LDS atomics, exclusive scan of the counts) and then writes them out slot by
+// slot: consecutive lanes store consecutive addresses within a destination's run, so a wavefront's store touches a
+// few lines instead of 64.
+static const uint32_t STAGE_ITEMS = 16384, STAGE_THREADS = 1024, STAGE_PER_THREAD = STAGE_ITEMS / STAGE_THREADS;
+static const uint32_t STAGE_MAX_BINS = 1024;
+// dynamic LDS: three tables of STAGE_MAX_BINS words, STAGE_ITEMS words of payload, STAGE_ITEMS bin numbers (16 bit)
+static const uint32_t STAGE_LDS_BYTES = 3 * STAGE_MAX_BINS * 4 + STAGE_ITEMS * 4 + STAGE_ITEMS * 2;
+
+// out[t] = sum of in[0..t) for t < count <= 1024, by the 1024 threads of the workgroup; returns the total.
+// wtot: 17 words of LDS.  Ends with a barrier; `in` and `out` may be the same array.
+__device__ __forceinline__ uint32_t stage_exclusive_scan(const uint32_t *in, uint32_t *out, uint32_t count, uint32_t *wtot) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t v = tid < count ? in[tid] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if ((tid & 63u) >= (uint32_t)d) incl += up;
+    }
+    if ((tid & 63u) == 63u) wtot[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) {
+        const uint32_t t = wtot[w];
+        if (w < (tid >> 6)) base += t;
+        total += t;
+    }
+    if (tid < count) out[tid] = base + incl - v;
+    __syncthreads();
+    return total;
+}
+
+// msm_range_kernel<1, .> with staged stores: same mid_key / mid_val contents up to the order inside a block's run
+__global__ void __launch_bounds__(STAGE_THREADS) msm_range_place_kernel(const uint32_t *dig, SortGeom g, uint32_t n_ranges,
+                                                                        uint32_t n_blocks, const uint32_t *blockcnt,
+                                                                        uint32_t *mid_key, uint32_t *mid_val) {
+    extern __shared__ uint32_t lds[];
+    __shared__ uint32_t wtot[17];
+    uint32_t *cnt = lds, *loc = lds + STAGE_MAX_BINS, *delta = lds + 2 * STAGE_MAX_BINS, *stage = lds + 3 * STAGE_MAX_BINS;
+    uint16_t *sbin = reinterpret_cast<uint16_t *>(stage + STAGE_ITEMS);
+    const uint32_t blk = blockIdx.x, tid = threadIdx.x;
+    if (tid < n_ranges) cnt[tid] = 0u;
+    __syncthreads();
+    const uint32_t lo = blk * STAGE_ITEMS, mask = (1u << g.log_range) - 1u;
+    uint32_t vv[STAGE_PER_THREAD], slot[STAGE_PER_THREAD];
+#pragma unroll
+    for (uint32_t u = 0; u < STAGE_PER_THREAD; u++) {
+        const uint32_t j = lo + u * STAGE_THREADS + tid;
+        vv[u] = j < g.n_items ? dig[j] : 0u;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < STAGE_PER_THREAD; u++) {
+        const uint32_t mag = vv[u] & 0x7fffffffu;
+        slot[u] = mag ? atomicAdd(&cnt[(mag - 1) >> g.log_range], 1u) : 0u;
+    }
+    __syncthreads();
+    const uint32_t total = stage_exclusive_scan(cnt, loc, n_ranges, wtot);
+    if (tid < n_ranges) delta[tid] = blockcnt[(size_t)tid * n_blocks + blk] - loc[tid];   // global position - slot
+    // keys
+#pragma unroll
+    for (uint32_t u = 0; u < STAGE_PER_THREAD; u++) {
+        const uint32_t mag = vv[u] & 0x7fffffffu;
+        if (!mag) continue;
+        const uint32_t b = mag - 1, r = b >> g.log_range;
+        slot[u] += loc[r];
+        stage[slot[u]] = (b & mask) | (vv[u] & 0x80000000u);
+        sbin[slot[u]] = (uint16_t)r;
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < total; k += STAGE_THREADS) mid_key[k + delta[sbin[k]]] = stage[k];
+    __syncthreads();
+    // table indexes
+#pragma unroll
+    for (uint32_t u = 0; u < STAGE_PER_THREAD; u++) {
+        if (!(vv[u] & 0x7fffffffu)) continue;
+        const uint32_t j = lo + u * STAGE_THREADS + tid;
+        const uint32_t w = j / g.n, i = j - w * g.n;
+        stage[slot[u]] = w * g.stride + g.base + i;
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < total; k += STAGE_THREADS) mid_val[k + delta[sbin[k]]] = stage[k];
+}
+
+// msm_sort2_kernel<1> with staged stores, for ranges of at most STAGE_MAX_BINS buckets: the slice is taken tile by
+// tile; a tile's entries are ordered by bucket in LDS and appended to their buckets' runs.  A range that fits one
+// tile (2^20 points) leaves the workgroup as one contiguous block.
+__global__ void __launch_bounds__(STAGE_THREADS) msm_sort3_kernel(const uint32_t *mid_key, const uint32_t *mid_val,
+                                                                  const uint32_t *range_start, uint32_t n_blocks, SortGeom g,
+                                                                  const uint32_t *part, uint32_t *sorted) {
+    extern __shared__ uint32_t lds[];
+    __shared__ uint32_t wtot[17];
+    uint32_t *cursor = lds, *tcnt = lds + STAGE_MAX_BINS, *toff = lds + 2 * STAGE_MAX_BINS, *stage = lds + 3 * STAGE_MAX_BINS;
+    uint16_t *sbkt = reinterpret_cast<uint16_t *>(stage + STAGE_ITEMS);
+    const uint32_t range = 1u << g.log_range, tid = threadIdx.x;
+    uint32_t s, r;
+    sort2_block(blockIdx.x, g.S, g.B >> g.log_range, s, r);
+    const uint32_t *mine = part + (size_t)s * g.B + ((size_t)r << g.log_range);
+    if (tid < range) {
+        cursor[tid] = mine[tid];
+        tcnt[tid] = 0u;
+    }
+    __syncthreads();
+    const uint32_t first = range_start[(size_t)r * n_blocks], last = range_start[(size_t)(r + 1) * n_blocks];
+    const uint32_t slice = (last - first + g.S - 1) / g.S;
+    const uint32_t lo = first + s * slice;
+    uint32_t hi = lo + slice;
+    if (hi > last) hi = last;
+    for (uint32_t t0 = lo; t0 < hi; t0 += STAGE_ITEMS) {
+        const uint32_t tile_n = hi - t0 < STAGE_ITEMS ? hi - t0 : STAGE_ITEMS;
+        uint32_t kk[STAGE_PER_THREAD], vv[STAGE_PER_THREAD], rk[STAGE_PER_THREAD];
+#pragma unroll
+        for (uint32_t u = 0; u < STAGE_PER_THREAD; u++) {
+            const uint32_t k = u * STAGE_THREADS + tid;
+            kk[u] = k < tile_n ? __builtin_nontemporal_load(mid_key + t0 + k) : 0xffffffffu;
+            vv[u] = k < tile_n ? __builtin_nontemporal_load(mid_val + t0 + k) : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < STAGE_PER_THREAD; u++)
+            rk[u] = (u * STAGE_THREADS + tid) < tile_n ? atomicAdd(&tcnt[kk[u] & 0x7fffffffu], 1u) : 0u;
+        __syncthreads();
+        stage_exclusive_scan(tcnt, toff, range, wtot);
+#pragma unroll
+        for (uint32_t u = 0; u < STAGE_PER_THREAD; u++) {
+            if ((u * STAGE_THREADS + tid) >= tile_n) continue;
+            const uint32_t b = kk[u] & 0x7fffffffu, at = toff[b] + rk[u];
+            stage[at] = vv[u] | (kk[u] & 0x80000000u);
+            sbkt[at] = (uint16_t)b;
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < tile_n; k += STAGE_THREADS) {
+            const uint32_t b = sbkt[k];
+            sorted[cursor[b] + (k - toff[b])] = stage[k];
+        }
+        __syncthreads();
+        if (tid < range) {
+            cursor[tid] += tcnt[tid];
+            tcnt[tid] = 0u;
+        }
+        __syncthreads();
+    }
+}
+
 // Workgroup (s, r) owns slice s of range r's items [range_start[r * n_blocks], range_start[(r + 1) * n_blocks]).
 template <int PASS>
 __global__ void __launch_bounds__(1024) msm_sort2_kernel(const uint32_t *mid_key, const uint32_t *mid_val,
@@ -1024,10 +1170,21 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     // sort geometry: up to 2^15 buckets sort in one level (128 KiB of LDS counters per workgroup); above that, ranges
     // of 2^13 buckets, whose output regions (a few MB at 2^20..2^22 points) sit in one XCD's L2 while they are written
     // (measured best among 2^9..2^14 at 2^20 and at 2^24 points); slices so that ~1024 workgroups exist
-    const uint32_t log_range = log_B <= 15 ? log_B : 13;
+    // Between 2^16 and 2^20 buckets the two placing passes stage their stores through LDS (msm_range_place_kernel,
+    // msm_sort3_kernel): 1024 ranges of at most 2^10 buckets.  Beyond that the ranges would outgrow the staged
+    // kernels' tables: ranges of 2^13 buckets and the lane-scattered kernels.
+    const bool staged = log_B > 15 && log_B <= 20;
+    const uint32_t log_range = log_B <= 15 ? log_B : staged ? (log_B > 19 ? log_B - 10 : 9) : 13;
+    const uint32_t RANGE_ITEMS = staged ? STAGE_ITEMS : RANGE_PER_THREAD * 256;
     const uint32_t n_ranges = 1u << (log_B - log_range);
+    // slices per range: one while a range's items are a few tiles; more for the largest inputs, which also bounds the
+    // time one workgroup spends on a range that repeated scalars have filled
     uint32_t S_max = 1024 / n_ranges;
     if (S_max < 1) S_max = 1;
+    if (staged) {
+        S_max = 1;
+        while (S_max < 8 && (max_items >> (log_B - log_range)) > (uint64_t)S_max * 4 * STAGE_ITEMS) S_max <<= 1;
+    }
     const size_t lds_bytes = (size_t)4 << log_range;
     if (!lds_attr_set_) {
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort_kernel<0>),
@@ -1038,6 +1195,10 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort2_kernel<1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_range_place_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_LDS_BYTES));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort3_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_LDS_BYTES));
         lds_attr_set_ = true;
     }
 
@@ -1126,13 +1287,21 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             uint32_t *range_sums = blockcnt + n_cnt;
             uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
             ZK_HIP(hipMemsetAsync(blockcnt + n_cnt - 1, 0, 4, stream_));
-            hipLaunchKernelGGL(msm_range_kernel<0>, dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
-                               blockcnt, mkey, mval);
+            if (staged)
+                hipLaunchKernelGGL((msm_range_kernel<0, STAGE_THREADS>), dim3(n_blocks), dim3(STAGE_THREADS), 0, stream_, dig[j], geom[j],
+                                   n_ranges, n_blocks, blockcnt, mkey, mval);
+            else
+                hipLaunchKernelGGL((msm_range_kernel<0, 256>), dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
+                                   blockcnt, mkey, mval);
             hipLaunchKernelGGL(scan_block_kernel, dim3(n_cnt_blocks), dim3(256), 0, stream_, blockcnt, blockcnt, range_sums, n_cnt);
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream_, range_sums, n_cnt_blocks);
             hipLaunchKernelGGL(scan_add_kernel, dim3(ceil_div(n_cnt, 256)), dim3(256), 0, stream_, blockcnt, range_sums, n_cnt);
-            hipLaunchKernelGGL(msm_range_kernel<1>, dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
-                               blockcnt, mkey, mval);
+            if (staged)
+                hipLaunchKernelGGL(msm_range_place_kernel, dim3(n_blocks), dim3(STAGE_THREADS), STAGE_LDS_BYTES, stream_, dig[j], geom[j],
+                                   n_ranges, n_blocks, blockcnt, mkey, mval);
+            else
+                hipLaunchKernelGGL((msm_range_kernel<1, 256>), dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
+                                   blockcnt, mkey, mval);
             if (m == 1) mark(2);   // with several sums the partitions and count passes alternate: all of it counts as partition
             // msm_range_kernel<1> advanced nothing in global memory: blockcnt still holds the start positions
             hipLaunchKernelGGL(msm_sort2_kernel<0>, dim3(geom[j].S * n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt, n_blocks,
@@ -1161,8 +1330,12 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             const uint32_t n_blocks = ceil_div(geom[j].n_items, RANGE_ITEMS);
             const uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
             const uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
-            hipLaunchKernelGGL(msm_sort2_kernel<1>, dim3(geom[j].S * n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt,
-                               n_blocks, geom[j], part, sorted_.as<uint32_t>());
+            if (staged)
+                hipLaunchKernelGGL(msm_sort3_kernel, dim3(geom[j].S * n_ranges), dim3(STAGE_THREADS), STAGE_LDS_BYTES, stream_, mkey, mval,
+                                   blockcnt, n_blocks, geom[j], part, sorted_.as<uint32_t>());
+            else
+                hipLaunchKernelGGL(msm_sort2_kernel<1>, dim3(geom[j].S * n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt,
+                                   n_blocks, geom[j], part, sorted_.as<uint32_t>());
         }
     }
     mark(5);

@@ -151,14 +151,33 @@ __device__ __forceinline__ void gstore_proj(G1Proj *p, const G1Proj &r) {
 // Geometry of one sum's counting sort: slice = ceil(n_items / S)
 struct SortGeom {
     uint32_t n_items, n, stride, base, B, log_range, S, slice;
+    // dyn != 0: S is only the most slices a range may have; a range takes as many as its item count asks for
+    // (range_slices), so that a range which repeated scalars have filled is shared by several workgroups
+    uint32_t dyn;
 };
+// Slices of a range with `count` items when at most `cap` are allowed: two staged tiles (2^15 items) per slice
+__device__ __forceinline__ uint32_t range_slices(uint32_t count, uint32_t cap) {
+    const uint32_t s = (count + 32767u) >> 15;
+    return s < 1u ? 1u : (s > cap ? cap : s);
+}
 // Per-sum arguments of a batch, passed by value: the small kernels below serve sum first_sum + blockIdx.y (or .z),
 // so one launch covers either a single sum or the whole batch.
 struct SumArgs {
     const Fr *scalars[MsmEngine::MAX_BATCH];
     uint32_t *dig[MsmEngine::MAX_BATCH];
     SortGeom g[MsmEngine::MAX_BATCH];
+    // two-level sort: start of every (range, block) run in the partitioned list, n_blocks entries per range + the total
+    const uint32_t *range_start[MsmEngine::MAX_BATCH];
+    uint32_t n_blocks[MsmEngine::MAX_BATCH];
 };
+// Slices that hold entries of bucket b of sum `sum`
+__device__ __forceinline__ uint32_t slices_of_bucket(const SumArgs &a, uint32_t sum, uint32_t b) {
+    const SortGeom &g = a.g[sum];
+    if (!g.dyn) return g.S;
+    const uint32_t r = b >> g.log_range, nbk = a.n_blocks[sum];
+    const uint32_t *rs = a.range_start[sum];
+    return range_slices(rs[(size_t)(r + 1) * nbk] - rs[(size_t)r * nbk], g.S);
+}
 
 // dig[w * n + i] = |digit| | sign << 31 of scalar i in window w (0 when the digit is zero)
 __global__ void __launch_bounds__(256) msm_digits_kernel(SumArgs a, uint32_t first_sum, uint32_t c, uint32_t K) {
@@ -339,6 +358,23 @@ __device__ __forceinline__ uint32_t stage_exclusive_scan(const uint32_t *in, uin
     return total;
 }
 
+// The (range, slice) pairs of a sum whose ranges take range_slices() slices each: tasks[0] = their number, then
+// range << 8 | slice in range order.  One workgroup of 1024 threads; n_ranges <= 1024.  The workgroups of the count
+// pass and of the placing pass take one task each, so a launch needs n_ranges + items / 2^15 workgroups at most.
+__global__ void __launch_bounds__(STAGE_THREADS) msm_slice_tasks_kernel(const uint32_t *range_start, uint32_t n_blocks,
+                                                                        uint32_t n_ranges, uint32_t cap, uint32_t *tasks) {
+    __shared__ uint32_t wtot[17], sl[STAGE_MAX_BINS], off[STAGE_MAX_BINS];
+    const uint32_t tid = threadIdx.x;
+    uint32_t mine = 0;
+    if (tid < n_ranges) mine = range_slices(range_start[(size_t)(tid + 1) * n_blocks] - range_start[(size_t)tid * n_blocks], cap);
+    sl[tid] = mine;
+    __syncthreads();
+    const uint32_t total = stage_exclusive_scan(sl, off, n_ranges, wtot);
+    if (tid < n_ranges)
+        for (uint32_t k = 0; k < mine; k++) tasks[1 + off[tid] + k] = (tid << 8) | k;
+    if (tid == 0) tasks[0] = total;
+}
+
 // msm_range_kernel<1, .> with staged stores: same mid_key / mid_val contents up to the order inside a block's run
 __global__ void __launch_bounds__(STAGE_THREADS) msm_range_place_kernel(const uint32_t *dig, SortGeom g, uint32_t n_ranges,
                                                                         uint32_t n_blocks, const uint32_t *blockcnt,
@@ -395,14 +431,14 @@ __global__ void __launch_bounds__(STAGE_THREADS) msm_range_place_kernel(const ui
 // tile (2^20 points) leaves the workgroup as one contiguous block.
 __global__ void __launch_bounds__(STAGE_THREADS) msm_sort3_kernel(const uint32_t *mid_key, const uint32_t *mid_val,
                                                                   const uint32_t *range_start, uint32_t n_blocks, SortGeom g,
-                                                                  const uint32_t *part, uint32_t *sorted) {
+                                                                  const uint32_t *tasks, const uint32_t *part, uint32_t *sorted) {
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wtot[17];
     uint32_t *cursor = lds, *tcnt = lds + STAGE_MAX_BINS, *toff = lds + 2 * STAGE_MAX_BINS, *stage = lds + 3 * STAGE_MAX_BINS;
     uint16_t *sbkt = reinterpret_cast<uint16_t *>(stage + STAGE_ITEMS);
     const uint32_t range = 1u << g.log_range, tid = threadIdx.x;
-    uint32_t s, r;
-    sort2_block(blockIdx.x, g.S, g.B >> g.log_range, s, r);
+    if (blockIdx.x >= tasks[0]) return;
+    const uint32_t task = tasks[1 + blockIdx.x], s = task & 0xffu, r = task >> 8;
     const uint32_t *mine = part + (size_t)s * g.B + ((size_t)r << g.log_range);
     if (tid < range) {
         cursor[tid] = mine[tid];
@@ -410,7 +446,8 @@ __global__ void __launch_bounds__(STAGE_THREADS) msm_sort3_kernel(const uint32_t
     }
     __syncthreads();
     const uint32_t first = range_start[(size_t)r * n_blocks], last = range_start[(size_t)(r + 1) * n_blocks];
-    const uint32_t slice = (last - first + g.S - 1) / g.S;
+    const uint32_t n_slices = range_slices(last - first, g.S);
+    const uint32_t slice = (last - first + n_slices - 1) / n_slices;
     const uint32_t lo = first + s * slice;
     uint32_t hi = lo + slice;
     if (hi > last) hi = last;
@@ -453,16 +490,24 @@ __global__ void __launch_bounds__(STAGE_THREADS) msm_sort3_kernel(const uint32_t
 template <int PASS>
 __global__ void __launch_bounds__(1024) msm_sort2_kernel(const uint32_t *mid_key, const uint32_t *mid_val,
                                                          const uint32_t *range_start, uint32_t n_blocks, SortGeom g,
-                                                         uint32_t *part, uint32_t *sorted) {
+                                                         const uint32_t *tasks, uint32_t *part, uint32_t *sorted) {
     extern __shared__ uint32_t hist[];
     const uint32_t range = 1u << g.log_range;
     uint32_t s, r;
-    sort2_block(blockIdx.x, g.S, g.B >> g.log_range, s, r);
+    if (g.dyn) {   // one (range, slice) task per workgroup
+        if (blockIdx.x >= tasks[0]) return;
+        const uint32_t task = tasks[1 + blockIdx.x];
+        s = task & 0xffu;
+        r = task >> 8;
+    } else {
+        sort2_block(blockIdx.x, g.S, g.B >> g.log_range, s, r);
+    }
     uint32_t *mine = part + (size_t)s * g.B + ((size_t)r << g.log_range);
     for (uint32_t t = threadIdx.x; t < range; t += blockDim.x) hist[t] = PASS ? mine[t] : 0u;
     __syncthreads();
     const uint32_t first = range_start[(size_t)r * n_blocks], last = range_start[(size_t)(r + 1) * n_blocks];
-    const uint32_t slice = (last - first + g.S - 1) / g.S;
+    const uint32_t n_slices = g.dyn ? range_slices(last - first, g.S) : g.S;   // counters of unused slices are never read
+    const uint32_t slice = (last - first + n_slices - 1) / n_slices;
     const uint32_t lo = first + s * slice;
     uint32_t hi = lo + slice;
     if (hi > last) hi = last;
@@ -492,11 +537,12 @@ __global__ void __launch_bounds__(1024) msm_sort2_kernel(const uint32_t *mid_key
 __global__ void __launch_bounds__(256) msm_totals_kernel(SumArgs a, uint32_t first_sum, const uint32_t *part, size_t part_stride,
                                                          uint32_t *counts) {
     const uint32_t sum = first_sum + blockIdx.y;
-    const uint32_t B = a.g[sum].B, S = a.g[sum].S;
+    const uint32_t B = a.g[sum].B;
     part += (size_t)sum * part_stride;
     counts += (size_t)sum * B;
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const uint32_t S = slices_of_bucket(a, sum, b);
     uint32_t tot = 0;
     for (uint32_t s = 0; s < S; s++) tot += part[(size_t)s * B + b];
     counts[b] = tot;
@@ -505,11 +551,12 @@ __global__ void __launch_bounds__(256) msm_totals_kernel(SumArgs a, uint32_t fir
 __global__ void __launch_bounds__(256) msm_cursors_kernel(SumArgs a, uint32_t first_sum, uint32_t *part, size_t part_stride,
                                                           const uint32_t *offsets) {
     const uint32_t sum = first_sum + blockIdx.y;
-    const uint32_t B = a.g[sum].B, S = a.g[sum].S;
+    const uint32_t B = a.g[sum].B;
     part += (size_t)sum * part_stride;
     offsets += (size_t)sum * B;
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const uint32_t S = slices_of_bucket(a, sum, b);
     uint32_t run = offsets[b];
     for (uint32_t s = 0; s < S; s++) {
         size_t idx = (size_t)s * B + b;
@@ -941,14 +988,14 @@ __global__ void __launch_bounds__(256) msm_powers_kernel(Fr tau, G1Affine g, uin
 // ---------------------------------------------------------------------------------------------------------
 MsmEngine::~MsmEngine() {
     DevBuf *all[] = {&points_, &counts_, &offsets_, &cursor_, &sorted_, &buckets_, &block_sums_, &tasks_, &partials_,
-                     &misc_,   &seg_,    &group_sums_, &order_, &digits_, &table28_, &range_cnt_, &mid_};
+                     &misc_,   &seg_,    &group_sums_, &order_, &digits_, &table28_, &range_cnt_, &mid_, &slice_tasks_};
     for (DevBuf *b : all) b->release();
     if (host_sums_) (void)hipHostFree(host_sums_);
 }
 
 size_t MsmEngine::device_bytes() const {
     return points_.cap + counts_.cap + offsets_.cap + cursor_.cap + sorted_.cap + buckets_.cap + block_sums_.cap +
-           tasks_.cap + partials_.cap + misc_.cap + seg_.cap + group_sums_.cap + order_.cap + digits_.cap + table28_.cap + range_cnt_.cap + mid_.cap;
+           tasks_.cap + partials_.cap + misc_.cap + seg_.cap + group_sums_.cap + order_.cap + digits_.cap + table28_.cap + range_cnt_.cap + mid_.cap + slice_tasks_.cap;
 }
 
 // Window width for a table of n points, from a time model (milliseconds) fitted to MI355X measurements
@@ -1177,14 +1224,9 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     const uint32_t log_range = log_B <= 15 ? log_B : staged ? (log_B > 19 ? log_B - 10 : 9) : 13;
     const uint32_t RANGE_ITEMS = staged ? STAGE_ITEMS : RANGE_PER_THREAD * 256;
     const uint32_t n_ranges = 1u << (log_B - log_range);
-    // slices per range: one while a range's items are a few tiles; more for the largest inputs, which also bounds the
-    // time one workgroup spends on a range that repeated scalars have filled
     uint32_t S_max = 1024 / n_ranges;
     if (S_max < 1) S_max = 1;
-    if (staged) {
-        S_max = 1;
-        while (S_max < 8 && (max_items >> (log_B - log_range)) > (uint64_t)S_max * 4 * STAGE_ITEMS) S_max <<= 1;
-    }
+    if (staged) S_max = 16;   // the most a range may take (SortGeom::dyn); an evenly filled range of 2^20 points takes one
     const size_t lds_bytes = (size_t)4 << log_range;
     if (!lds_attr_set_) {
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort_kernel<0>),
@@ -1209,6 +1251,8 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
         range_cnt_.reserve((size_t)m * range_cnt_stride * 4);
         mid_.reserve((size_t)m * 2 * max_items * 4);
     }
+    const size_t slice_tasks_stride = staged ? (size_t)n_ranges + (size_t)(max_items >> 15) + 2 : 0;
+    if (staged) slice_tasks_.reserve((size_t)m * slice_tasks_stride * 4);
     counts_.reserve((size_t)nb * 4);
     offsets_.reserve((size_t)nb * 4);
     cursor_.reserve((size_t)nb * S_max * 4);            // per-(sum, slice, bucket) counts, then cursors
@@ -1247,7 +1291,8 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
         const uint32_t k = j < m ? j : 0;   // unused entries repeat sum 0
         const uint64_t n_items = (uint64_t)lens[k] * K;
         uint32_t S = S_max;
-        while (S > 1 && n_items / S < 16384) S >>= 1;  // keep slices long enough to amortise the histogram flush
+        if (!staged)
+            while (S > 1 && n_items / S < 16384) S >>= 1;  // keep slices long enough to amortise the histogram flush
         geom[j].n_items = (uint32_t)n_items;
         geom[j].n = (uint32_t)lens[k];
         geom[j].stride = (uint32_t)n_points_;
@@ -1256,6 +1301,9 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
         geom[j].log_range = log_range;
         geom[j].S = S;
         geom[j].slice = (uint32_t)((n_items + S - 1) / S);
+        geom[j].dyn = staged ? 1u : 0u;
+        sums.range_start[j] = nullptr;
+        sums.n_blocks[j] = 0;
         sums.scalars[j] = scalars_dev[k];
         if (j < m) {
             dig[j] = digits_.as<uint32_t>() + item_base;
@@ -1286,6 +1334,8 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
             uint32_t *range_sums = blockcnt + n_cnt;
             uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
+            sums.range_start[j] = blockcnt;
+            sums.n_blocks[j] = n_blocks;
             ZK_HIP(hipMemsetAsync(blockcnt + n_cnt - 1, 0, 4, stream_));
             if (staged)
                 hipLaunchKernelGGL((msm_range_kernel<0, STAGE_THREADS>), dim3(n_blocks), dim3(STAGE_THREADS), 0, stream_, dig[j], geom[j],
@@ -1302,10 +1352,17 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             else
                 hipLaunchKernelGGL((msm_range_kernel<1, 256>), dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
                                    blockcnt, mkey, mval);
+            uint32_t *tasks = nullptr, sort_grid = geom[j].S * n_ranges;
+            if (staged) {
+                sort_grid = n_ranges + (uint32_t)(n_items >> 15) + 1;
+                tasks = slice_tasks_.as<uint32_t>() + (size_t)j * slice_tasks_stride;
+                hipLaunchKernelGGL(msm_slice_tasks_kernel, dim3(1), dim3(STAGE_THREADS), 0, stream_, blockcnt, n_blocks, n_ranges,
+                                   geom[j].S, tasks);
+            }
             if (m == 1) mark(2);   // with several sums the partitions and count passes alternate: all of it counts as partition
             // msm_range_kernel<1> advanced nothing in global memory: blockcnt still holds the start positions
-            hipLaunchKernelGGL(msm_sort2_kernel<0>, dim3(geom[j].S * n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt, n_blocks,
-                               geom[j], part, sorted_.as<uint32_t>());
+            hipLaunchKernelGGL(msm_sort2_kernel<0>, dim3(sort_grid), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt, n_blocks,
+                               geom[j], tasks, part, sorted_.as<uint32_t>());
         }
         if (m > 1) mark(2);
     }
@@ -1331,11 +1388,12 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             const uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
             const uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
             if (staged)
-                hipLaunchKernelGGL(msm_sort3_kernel, dim3(geom[j].S * n_ranges), dim3(STAGE_THREADS), STAGE_LDS_BYTES, stream_, mkey, mval,
-                                   blockcnt, n_blocks, geom[j], part, sorted_.as<uint32_t>());
+                hipLaunchKernelGGL(msm_sort3_kernel, dim3(n_ranges + (geom[j].n_items >> 15) + 1), dim3(STAGE_THREADS), STAGE_LDS_BYTES,
+                                   stream_, mkey, mval, blockcnt, n_blocks, geom[j],
+                                   slice_tasks_.as<uint32_t>() + (size_t)j * slice_tasks_stride, part, sorted_.as<uint32_t>());
             else
                 hipLaunchKernelGGL(msm_sort2_kernel<1>, dim3(geom[j].S * n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt,
-                                   n_blocks, geom[j], part, sorted_.as<uint32_t>());
+                                   n_blocks, geom[j], nullptr, part, sorted_.as<uint32_t>());
         }
     }
     mark(5);

@@ -80,7 +80,7 @@ class MsmEngine {
     size_t n_points_ = 0;
     uint32_t c_ = 0, K_ = 0, seg_bits_ = 0;
     DevBuf counts_, offsets_, cursor_, sorted_, buckets_, block_sums_, tasks_, partials_, misc_, seg_, group_sums_;
-    DevBuf order_, digits_, range_cnt_, mid_;
+    DevBuf order_, digits_, range_cnt_, mid_, slice_tasks_;
     uint32_t window_override_ = 0;
     hipEvent_t *profile_ = nullptr;
     bool lds_attr_set_ = false;

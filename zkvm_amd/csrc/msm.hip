@@ -328,10 +328,10 @@ __device__ __forceinline__ void sort2_block(uint32_t lin, uint32_t S, uint32_t n
 // items by destination in LDS (rank by LDS atomics, exclusive scan of the counts) and then writes them out slot by
 // slot: consecutive lanes store consecutive addresses within a destination's run, so a wavefront's store touches a
 // few lines instead of 64.
-static const uint32_t STAGE_ITEMS = 16384, STAGE_THREADS = 1024, STAGE_PER_THREAD = STAGE_ITEMS / STAGE_THREADS;
+static const uint32_t STAGE_ITEMS = 16384, STAGE_THREADS = 1024;
 static const uint32_t STAGE_MAX_BINS = 1024;
-// dynamic LDS: three tables of STAGE_MAX_BINS words, STAGE_ITEMS words of payload, STAGE_ITEMS bin numbers (16 bit)
-static const uint32_t STAGE_LDS_BYTES = 3 * STAGE_MAX_BINS * 4 + STAGE_ITEMS * 4 + STAGE_ITEMS * 2;
+// dynamic LDS for tiles of TILE items: three tables of STAGE_MAX_BINS words, TILE words of payload, TILE bin numbers (16 bit)
+static constexpr uint32_t stage_lds_bytes(uint32_t tile) { return 3 * STAGE_MAX_BINS * 4 + tile * 4 + tile * 2; }
 
 // out[t] = sum of in[0..t) for t < count <= 1024, by the 1024 threads of the workgroup; returns the total.
 // wtot: 17 words of LDS.  Ends with a barrier; `in` and `out` may be the same array.
@@ -375,67 +375,92 @@ __global__ void __launch_bounds__(STAGE_THREADS) msm_slice_tasks_kernel(const ui
     if (tid == 0) tasks[0] = total;
 }
 
-// msm_range_kernel<1, .> with staged stores: same mid_key / mid_val contents up to the order inside a block's run
+// msm_range_kernel<1, .> with staged stores: same mid_key / mid_val contents up to the order inside a block's run.
+// The block of STAGE_ITEMS items (the unit of the count pass) is taken in tiles of TILE.  Tiles of 2^13 items would
+// let two workgroups share a CU; measured slower than one tile of 2^14 (shorter runs), in this pass and in the final
+// one.
+template <uint32_t TILE>
 __global__ void __launch_bounds__(STAGE_THREADS) msm_range_place_kernel(const uint32_t *dig, SortGeom g, uint32_t n_ranges,
                                                                         uint32_t n_blocks, const uint32_t *blockcnt,
                                                                         uint32_t *mid_key, uint32_t *mid_val) {
+    constexpr uint32_t PER_THREAD = TILE / STAGE_THREADS;
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wtot[17];
-    uint32_t *cnt = lds, *loc = lds + STAGE_MAX_BINS, *delta = lds + 2 * STAGE_MAX_BINS, *stage = lds + 3 * STAGE_MAX_BINS;
-    uint16_t *sbin = reinterpret_cast<uint16_t *>(stage + STAGE_ITEMS);
+    uint32_t *cnt = lds, *loc = lds + STAGE_MAX_BINS, *gpos = lds + 2 * STAGE_MAX_BINS, *stage = lds + 3 * STAGE_MAX_BINS;
+    uint16_t *sbin = reinterpret_cast<uint16_t *>(stage + TILE);
     const uint32_t blk = blockIdx.x, tid = threadIdx.x;
-    if (tid < n_ranges) cnt[tid] = 0u;
-    __syncthreads();
-    const uint32_t lo = blk * STAGE_ITEMS, mask = (1u << g.log_range) - 1u;
-    uint32_t vv[STAGE_PER_THREAD], slot[STAGE_PER_THREAD];
-#pragma unroll
-    for (uint32_t u = 0; u < STAGE_PER_THREAD; u++) {
-        const uint32_t j = lo + u * STAGE_THREADS + tid;
-        vv[u] = j < g.n_items ? dig[j] : 0u;
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < STAGE_PER_THREAD; u++) {
-        const uint32_t mag = vv[u] & 0x7fffffffu;
-        slot[u] = mag ? atomicAdd(&cnt[(mag - 1) >> g.log_range], 1u) : 0u;
+    if (tid < n_ranges) {
+        cnt[tid] = 0u;
+        gpos[tid] = blockcnt[(size_t)tid * n_blocks + blk];   // where this block's next item of the range goes
     }
     __syncthreads();
-    const uint32_t total = stage_exclusive_scan(cnt, loc, n_ranges, wtot);
-    if (tid < n_ranges) delta[tid] = blockcnt[(size_t)tid * n_blocks + blk] - loc[tid];   // global position - slot
-    // keys
+    const uint32_t mask = (1u << g.log_range) - 1u;
+    for (uint32_t t0 = 0; t0 < STAGE_ITEMS; t0 += TILE) {
+        const uint32_t lo = blk * STAGE_ITEMS + t0;
+        if (lo >= g.n_items) break;   // uniform
+        uint32_t vv[PER_THREAD], slot[PER_THREAD];
 #pragma unroll
-    for (uint32_t u = 0; u < STAGE_PER_THREAD; u++) {
-        const uint32_t mag = vv[u] & 0x7fffffffu;
-        if (!mag) continue;
-        const uint32_t b = mag - 1, r = b >> g.log_range;
-        slot[u] += loc[r];
-        stage[slot[u]] = (b & mask) | (vv[u] & 0x80000000u);
-        sbin[slot[u]] = (uint16_t)r;
-    }
-    __syncthreads();
-    for (uint32_t k = tid; k < total; k += STAGE_THREADS) mid_key[k + delta[sbin[k]]] = stage[k];
-    __syncthreads();
-    // table indexes
+        for (uint32_t u = 0; u < PER_THREAD; u++) {
+            const uint32_t j = lo + u * STAGE_THREADS + tid;
+            vv[u] = j < g.n_items ? dig[j] : 0u;
+        }
 #pragma unroll
-    for (uint32_t u = 0; u < STAGE_PER_THREAD; u++) {
-        if (!(vv[u] & 0x7fffffffu)) continue;
-        const uint32_t j = lo + u * STAGE_THREADS + tid;
-        const uint32_t w = j / g.n, i = j - w * g.n;
-        stage[slot[u]] = w * g.stride + g.base + i;
+        for (uint32_t u = 0; u < PER_THREAD; u++) {
+            const uint32_t mag = vv[u] & 0x7fffffffu;
+            slot[u] = mag ? atomicAdd(&cnt[(mag - 1) >> g.log_range], 1u) : 0u;
+        }
+        __syncthreads();
+        const uint32_t total = stage_exclusive_scan(cnt, loc, n_ranges, wtot);
+        // keys
+#pragma unroll
+        for (uint32_t u = 0; u < PER_THREAD; u++) {
+            const uint32_t mag = vv[u] & 0x7fffffffu;
+            if (!mag) continue;
+            const uint32_t b = mag - 1, r = b >> g.log_range;
+            slot[u] += loc[r];
+            stage[slot[u]] = (b & mask) | (vv[u] & 0x80000000u);
+            sbin[slot[u]] = (uint16_t)r;
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < total; k += STAGE_THREADS) {
+            const uint32_t r = sbin[k];
+            mid_key[gpos[r] + (k - loc[r])] = stage[k];
+        }
+        __syncthreads();
+        // table indexes
+#pragma unroll
+        for (uint32_t u = 0; u < PER_THREAD; u++) {
+            if (!(vv[u] & 0x7fffffffu)) continue;
+            const uint32_t j = lo + u * STAGE_THREADS + tid;
+            const uint32_t w = j / g.n, i = j - w * g.n;
+            stage[slot[u]] = w * g.stride + g.base + i;
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < total; k += STAGE_THREADS) {
+            const uint32_t r = sbin[k];
+            mid_val[gpos[r] + (k - loc[r])] = stage[k];
+        }
+        __syncthreads();
+        if (tid < n_ranges) {
+            gpos[tid] += cnt[tid];
+            cnt[tid] = 0u;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (uint32_t k = tid; k < total; k += STAGE_THREADS) mid_val[k + delta[sbin[k]]] = stage[k];
 }
 
 // msm_sort2_kernel<1> with staged stores, for ranges of at most STAGE_MAX_BINS buckets: the slice is taken tile by
 // tile; a tile's entries are ordered by bucket in LDS and appended to their buckets' runs.  A range that fits one
 // tile (2^20 points) leaves the workgroup as one contiguous block.
+template <uint32_t TILE>
 __global__ void __launch_bounds__(STAGE_THREADS) msm_sort3_kernel(const uint32_t *mid_key, const uint32_t *mid_val,
                                                                   const uint32_t *range_start, uint32_t n_blocks, SortGeom g,
                                                                   const uint32_t *tasks, const uint32_t *part, uint32_t *sorted) {
+    constexpr uint32_t PER_THREAD = TILE / STAGE_THREADS;
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wtot[17];
     uint32_t *cursor = lds, *tcnt = lds + STAGE_MAX_BINS, *toff = lds + 2 * STAGE_MAX_BINS, *stage = lds + 3 * STAGE_MAX_BINS;
-    uint16_t *sbkt = reinterpret_cast<uint16_t *>(stage + STAGE_ITEMS);
+    uint16_t *sbkt = reinterpret_cast<uint16_t *>(stage + TILE);
     const uint32_t range = 1u << g.log_range, tid = threadIdx.x;
     if (blockIdx.x >= tasks[0]) return;
     const uint32_t task = tasks[1 + blockIdx.x], s = task & 0xffu, r = task >> 8;
@@ -451,22 +476,22 @@ __global__ void __launch_bounds__(STAGE_THREADS) msm_sort3_kernel(const uint32_t
     const uint32_t lo = first + s * slice;
     uint32_t hi = lo + slice;
     if (hi > last) hi = last;
-    for (uint32_t t0 = lo; t0 < hi; t0 += STAGE_ITEMS) {
-        const uint32_t tile_n = hi - t0 < STAGE_ITEMS ? hi - t0 : STAGE_ITEMS;
-        uint32_t kk[STAGE_PER_THREAD], vv[STAGE_PER_THREAD], rk[STAGE_PER_THREAD];
+    for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
+        const uint32_t tile_n = hi - t0 < TILE ? hi - t0 : TILE;
+        uint32_t kk[PER_THREAD], vv[PER_THREAD], rk[PER_THREAD];
 #pragma unroll
-        for (uint32_t u = 0; u < STAGE_PER_THREAD; u++) {
+        for (uint32_t u = 0; u < PER_THREAD; u++) {
             const uint32_t k = u * STAGE_THREADS + tid;
             kk[u] = k < tile_n ? __builtin_nontemporal_load(mid_key + t0 + k) : 0xffffffffu;
             vv[u] = k < tile_n ? __builtin_nontemporal_load(mid_val + t0 + k) : 0u;
         }
 #pragma unroll
-        for (uint32_t u = 0; u < STAGE_PER_THREAD; u++)
+        for (uint32_t u = 0; u < PER_THREAD; u++)
             rk[u] = (u * STAGE_THREADS + tid) < tile_n ? atomicAdd(&tcnt[kk[u] & 0x7fffffffu], 1u) : 0u;
         __syncthreads();
         stage_exclusive_scan(tcnt, toff, range, wtot);
 #pragma unroll
-        for (uint32_t u = 0; u < STAGE_PER_THREAD; u++) {
+        for (uint32_t u = 0; u < PER_THREAD; u++) {
             if ((u * STAGE_THREADS + tid) >= tile_n) continue;
             const uint32_t b = kk[u] & 0x7fffffffu, at = toff[b] + rk[u];
             stage[at] = vv[u] | (kk[u] & 0x80000000u);
@@ -1237,10 +1262,10 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort2_kernel<1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_range_place_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_LDS_BYTES));
-        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort3_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, STAGE_LDS_BYTES));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_range_place_kernel<16384>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, stage_lds_bytes(16384)));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort3_kernel<16384>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, stage_lds_bytes(16384)));
         lds_attr_set_ = true;
     }
 
@@ -1347,8 +1372,8 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream_, range_sums, n_cnt_blocks);
             hipLaunchKernelGGL(scan_add_kernel, dim3(ceil_div(n_cnt, 256)), dim3(256), 0, stream_, blockcnt, range_sums, n_cnt);
             if (staged)
-                hipLaunchKernelGGL(msm_range_place_kernel, dim3(n_blocks), dim3(STAGE_THREADS), STAGE_LDS_BYTES, stream_, dig[j], geom[j],
-                                   n_ranges, n_blocks, blockcnt, mkey, mval);
+                hipLaunchKernelGGL(msm_range_place_kernel<16384>, dim3(n_blocks), dim3(STAGE_THREADS), stage_lds_bytes(16384), stream_,
+                                   dig[j], geom[j], n_ranges, n_blocks, blockcnt, mkey, mval);
             else
                 hipLaunchKernelGGL((msm_range_kernel<1, 256>), dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
                                    blockcnt, mkey, mval);
@@ -1388,8 +1413,8 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             const uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
             const uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
             if (staged)
-                hipLaunchKernelGGL(msm_sort3_kernel, dim3(n_ranges + (geom[j].n_items >> 15) + 1), dim3(STAGE_THREADS), STAGE_LDS_BYTES,
-                                   stream_, mkey, mval, blockcnt, n_blocks, geom[j],
+                hipLaunchKernelGGL(msm_sort3_kernel<16384>, dim3(n_ranges + (geom[j].n_items >> 15) + 1), dim3(STAGE_THREADS),
+                                   stage_lds_bytes(16384), stream_, mkey, mval, blockcnt, n_blocks, geom[j],
                                    slice_tasks_.as<uint32_t>() + (size_t)j * slice_tasks_stride, part, sorted_.as<uint32_t>());
             else
                 hipLaunchKernelGGL(msm_sort2_kernel<1>, dim3(geom[j].S * n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt,

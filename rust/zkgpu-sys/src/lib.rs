@@ -111,6 +111,8 @@ extern "C" {
     pub fn zkgpu_prover_key_poly(ctx: *mut zkgpu_ctx, which: c_int, out: *mut u64) -> c_int;
     pub fn zkgpu_prover_key_eval8n(ctx: *mut zkgpu_ctx, which: c_int, out: *mut u64) -> c_int;
     pub fn zkgpu_prover_key_eval_len(ctx: *const zkgpu_ctx) -> usize;
+    pub fn zkgpu_prover_force_full_coset(ctx: *mut zkgpu_ctx, on: c_int) -> c_int;
+    pub fn zkgpu_prover_last_proof_coset(ctx: *const zkgpu_ctx) -> c_int;
     pub fn zkgpu_quotient(ctx: *mut zkgpu_ctx, polys: *const u64, lens: *const usize, challenges7: *const u64,
                           t_out: *mut u64, t_len: *mut usize) -> c_int;
     pub fn zkgpu_quotient_kernel_ms(ctx: *mut zkgpu_ctx, ms: *mut f32) -> c_int;

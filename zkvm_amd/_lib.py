@@ -84,6 +84,8 @@ SIGNATURES = {
     "zkgpu_prover_key_poly": (C.c_int, [_P, C.c_int, _P]),
     "zkgpu_prover_key_eval_len": (C.c_size_t, [_P]),
     "zkgpu_prover_key_eval8n": (C.c_int, [_P, C.c_int, _P]),
+    "zkgpu_prover_force_full_coset": (C.c_int, [_P, C.c_int]),
+    "zkgpu_prover_last_proof_coset": (C.c_int, [_P]),
     "zkgpu_quotient": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_size_t)]),
     "zkgpu_quotient_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "zkgpu_perm_z": (C.c_int, [_P, C.c_uint32, _P, _P, _P, _P, _P]),

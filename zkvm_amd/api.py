@@ -73,6 +73,11 @@ class Context:
                 raise cls(msg)
             raise ZkGpuError(rc, msg)
 
+    def force_full_coset(self, on=True):
+        """Keys loaded from now on evaluate the quotient over the reference's 8n coset whatever their gates
+        (zkgpu_prover_force_full_coset)."""
+        self._check(self._lib.zkgpu_prover_force_full_coset(self._h, 1 if on else 0))
+
     def sync(self):
         self._check(self._lib.zkgpu_sync(self._h))
 
@@ -465,7 +470,8 @@ class Prover:
         self.ctx._check(self.ctx._lib.zkgpu_prove(self.ctx._h, w_ptr, pi.ctypes.data if pi.size else None,
                                                   pi.shape[0], bl.ctypes.data, comms.ctypes.data, inf.ctypes.data,
                                                   evals.ctypes.data, chal.ctypes.data, tm if timings else None))
-        out = dict(comms=comms, comms_inf=inf, evals=evals, challenges=chal)
+        out = dict(comms=comms, comms_inf=inf, evals=evals, challenges=chal,
+                   coset=int(self.ctx._lib.zkgpu_prover_last_proof_coset(self.ctx._h)))
         if timings:
             out["timings_ms"] = dict(zip(PHASE_NAMES, [float(x) for x in tm]))
         return out

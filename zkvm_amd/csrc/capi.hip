@@ -659,6 +659,15 @@ int zkgpu_prover_key_eval8n(zkgpu_ctx *ctx, int which, uint64_t *out) {
     });
 }
 
+int zkgpu_prover_force_full_coset(zkgpu_ctx *ctx, int on) {
+    return guarded(ctx, [&] { ctx->prover->force_full_coset(on != 0); });
+}
+
+int zkgpu_prover_last_proof_coset(const zkgpu_ctx *ctx) {
+    if (!ctx || !ctx->prover->proved_once()) return 0;
+    return ctx->prover->last_proof_half_coset() ? 4 : 8;
+}
+
 int zkgpu_quotient(zkgpu_ctx *ctx, const uint64_t *polys, const size_t lens[6], const uint64_t *challenges7,
                    uint64_t *t_out, size_t *t_len) {
     return guarded(ctx, [&] {

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) perm_finish_kernel(const Fr *pnum_incl, c
 }
 
 void PolyEngine::permutation_z(const Fr *const wires[4], const Fr *const sigma_evals[4], const Fr &beta, const Fr &gamma,
-                               const Fr *roots_half, uint32_t n, Fr *z_out) {
+                               const Fr *roots_half, uint32_t n, Fr *z_out, bool *closed) {
     ZK_REQUIRE(n >= 1, ZKGPU_ERR_INVALID_ARG, "permutation_z: empty domain");
     s0_.reserve((size_t)n * sizeof(Fr));
     s1_.reserve((size_t)n * sizeof(Fr));
@@ -201,10 +201,65 @@ void PolyEngine::permutation_z(const Fr *const wires[4], const Fr *const sigma_e
     inclusive_scan<OpMul, true>(stream_, den, den, n, s2_);
     // the one inversion of the whole accumulator: a single field element, so it is cheaper on the host than as a
     // ~100k-instruction dependent chain on one GPU lane
-    Fr total;
+    Fr total, total_num;
     ZK_HIP(hipMemcpyAsync(&total, den, sizeof(Fr), hipMemcpyDeviceToHost, stream_));
+    if (closed) ZK_HIP(hipMemcpyAsync(&total_num, num + (n - 1), sizeof(Fr), hipMemcpyDeviceToHost, stream_));
     ZK_HIP(hipStreamSynchronize(stream_));
+    if (closed) *closed = !total.is_zero() && total_num == total;
     hipLaunchKernelGGL(perm_finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, num, den, Fr::inv(total), n, z_out);
+    ZK_HIP(hipGetLastError());
+}
+
+// ---- arithmetic gate, row by row ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gate_check_kernel(const Fr *wires, const Fr *sel_h, const Fr *pi, uint32_t n, uint32_t *flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr a = ld(wires + i), b = ld(wires + n + i), c = ld(wires + 2 * (size_t)n + i), d = ld(wires + 3 * (size_t)n + i);
+    Fr t = Fr::mul(Fr::mul(a, b), ld(sel_h + i));
+    t = Fr::add(t, Fr::mul(a, ld(sel_h + (size_t)n + i)));
+    t = Fr::add(t, Fr::mul(b, ld(sel_h + 2 * (size_t)n + i)));
+    t = Fr::add(t, Fr::mul(c, ld(sel_h + 3 * (size_t)n + i)));
+    t = Fr::add(t, Fr::mul(d, ld(sel_h + 4 * (size_t)n + i)));
+    t = Fr::add(t, ld(sel_h + 5 * (size_t)n + i));
+    t = Fr::add(Fr::mul(t, ld(sel_h + 6 * (size_t)n + i)), ld(pi + i));
+    if (!t.is_zero()) *flag = 1u;   // every writer stores the same value
+}
+void PolyEngine::gate_check(const Fr *wires, const Fr *sel_h, const Fr *pi, uint32_t n, uint32_t *flag_dev) {
+    if (!n) return;
+    hipLaunchKernelGGL(gate_check_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, wires, sel_h, pi, n, flag_dev);
+    ZK_HIP(hipGetLastError());
+}
+
+struct WindowArgs {
+    const Fr *src[8];
+    uint64_t first[8];
+    uint32_t m, count;
+};
+__global__ void gather_windows_kernel(WindowArgs a, Fr *dst) {
+    const uint32_t j = threadIdx.x / 8, i = threadIdx.x % 8;
+    if (j < a.m && i < a.count) st(dst + j * a.count + i, ld(a.src[j] + a.first[j] + i));
+}
+void PolyEngine::gather_windows(uint32_t m, const Fr *const *src, const uint64_t *first, uint32_t count, Fr *dst) {
+    ZK_REQUIRE(m <= 8 && count <= 8, ZKGPU_ERR_INVALID_ARG, "gather_windows: at most 8 windows of 8 elements");
+    if (!m || !count) return;
+    WindowArgs a;
+    a.m = m;
+    a.count = count;
+    for (uint32_t j = 0; j < m; j++) {
+        a.src[j] = src[j];
+        a.first[j] = first[j];
+    }
+    hipLaunchKernelGGL(gather_windows_kernel, dim3(1), dim3(64), 0, stream_, a, dst);
+    ZK_HIP(hipGetLastError());
+}
+
+__global__ void __launch_bounds__(256) take_even_kernel(const Fr *src, uint64_t count, Fr *dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) st(dst + i, ld(src + 2 * i));
+}
+void PolyEngine::take_even(const Fr *src, uint64_t count, Fr *dst) {
+    if (!count) return;
+    hipLaunchKernelGGL(take_even_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, stream_, src, count, dst);
     ZK_HIP(hipGetLastError());
 }
 

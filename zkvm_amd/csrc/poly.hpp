@@ -54,8 +54,21 @@ class PolyEngine {
 
     // z[0] = 1, z[i+1] = z[i] * prod_w (wire_w[i] + beta k_w root^i + gamma) / prod_w (wire_w[i] + beta sigma_w[i] + gamma)
     // (plonk/src/composer/permutation.rs:181-245).  `roots` = w^i for i < n/2 (the rest is -w^(i-n/2)).
+    // `closed`, when given, tells whether the product of all n numerators equals that of all n denominators (and is
+    // not zero): the accumulator then returns to 1 after the last row, which is what makes the permutation terms of the
+    // quotient's numerator vanish on the domain.
     void permutation_z(const Fr *const wires[4], const Fr *const sigma_evals[4], const Fr &beta, const Fr &gamma,
-                       const Fr *roots_half, uint32_t n, Fr *z_out);
+                       const Fr *roots_half, uint32_t n, Fr *z_out, bool *closed = nullptr);
+    // Row-wise check of the arithmetic gate (plonk/src/proof_system/widget/arithmetic/proverkey.rs:43-73 on the domain
+    // itself): *flag_dev is set to 1 when (a b q_m + a q_l + b q_r + c q_o + d q_4 + q_c) q_arith + PI differs from
+    // zero in some row.  wires = 4 x n values, sel_h = the 7 x n values of q_m q_l q_r q_o q_4 q_c q_arith, pi = n dense
+    // public inputs.  The caller clears the flag.
+    void gate_check(const Fr *wires, const Fr *sel_h, const Fr *pi, uint32_t n, uint32_t *flag_dev);
+    // dst[j * count + i] = src[j][first[j] + i] for j < m <= 8, i < count <= 8: a few coefficients of several vectors
+    // gathered for one copy to the host
+    void gather_windows(uint32_t m, const Fr *const *src, const uint64_t *first, uint32_t count, Fr *dst);
+    // dst[i] = src[2 i] for i < count
+    void take_even(const Fr *src, uint64_t count, Fr *dst);
     // Pointwise quotient over the 8n coset (plonk/src/proof_system/quotient_poly.rs:88-95,128-190,218-234).
     void quotient(const QuotientArgs &args);
     // Milliseconds the most recent quotient launch took on the device (HIP events recorded around every launch);

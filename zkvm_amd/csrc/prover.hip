@@ -83,14 +83,26 @@ Prover::~Prover() {
     work_.release();
     small_.release();
     pi_lagrange_.release();
+    evals4_.release();
+    sel_h_.release();
+    tops_dev_.release();
+    if (tops_host_) (void)hipHostFree(tops_host_);
     if (sums_ready_) (void)hipEventDestroy(sums_ready_);
 }
 
 size_t Prover::device_bytes() const {
-    return polys_.cap + evals_.cap + sigma_.cap + work_.cap + small_.cap + pi_lagrange_.cap;
+    return polys_.cap + evals_.cap + sigma_.cap + work_.cap + small_.cap + pi_lagrange_.cap + evals4_.cap + sel_h_.cap +
+           tops_dev_.cap;
 }
 
-const Fr *Prover::key_eval8n(int k) const { return reinterpret_cast<const Fr *>(evals_.p) + (size_t)k * ev_len_; }
+const Fr *Prover::key_eval8n(int k) {
+    ensure_evals8n();
+    return reinterpret_cast<const Fr *>(evals_.p) + (size_t)k * ev_len_;
+}
+
+void Prover::coset_fft_4n(const Fr *coeffs, uint64_t len, Fr *out) {
+    ntt_.transform(NTT_COSET_FFT, coeffs, len, out, log_n_ + 2);
+}
 
 void Prover::set_collective(uint32_t rank, uint32_t world, Collective::Fn fn, void *user) {
     ZK_REQUIRE(fn == nullptr || (world >= 1 && rank < world), ZKGPU_ERR_INVALID_ARG, "set_collective: rank outside the world");
@@ -191,28 +203,38 @@ void Prover::set_sharding(uint64_t shard_base, uint64_t total_points, uint32_t w
     world_ = fn ? world : 1;
 }
 
-// compiler.rs:303-306: linear_evaluations = coset_fft([0, 1]); L1 = coset_fft(ifft([1, 0, 0, ...]))
-// (quotient_poly.rs:237-245 builds alpha^2 * L1 per proof; alpha^2 is applied inside the quotient kernel);
-// compute_vanishing_poly_over_coset (domain.rs:256-275): v_h[i] = g^n * w_8n^(n i) - 1, period 8.
-void Prover::build_l1_and_vanishing(bool with_linear) {
-    const uint32_t n = n_, log_n = log_n_;
-    const size_t N8 = (size_t)8 * n;
-    Fr *evals = evals_.as<Fr>();
-    Fr *tmp = work_.as<Fr>();
+// compiler.rs:241-301: the selector and sigma polynomials over the coset; compiler.rs:303-306: linear_evaluations =
+// coset_fft([0, 1]); L1 = coset_fft(ifft([1, 0, 0, ...])) (quotient_poly.rs:237-245 builds alpha^2 * L1 per proof;
+// alpha^2 is applied inside the quotient kernel).
+void Prover::build_key_evals(bool half, Fr *evals, size_t stride, Fr *tmp, bool with_selectors, bool with_linear) {
+    const uint32_t n = n_;
+    auto forward = [&](const Fr *coeffs, uint64_t len, Fr *out) {
+        if (half)
+            coset_fft_4n(coeffs, len, out);
+        else
+            coset_fft_8n(coeffs, len, out);
+    };
+    if (with_selectors)
+        for (int k = 0; k < N_SEL; k++) forward(key_poly(k), poly_len_[k], evals + (size_t)k * stride);
     if (with_linear) {
         std::vector<Fr> two(2);
         two[0] = Fr::zero();
         two[1] = Fr::one();
         ZK_HIP(hipMemcpyAsync(tmp, two.data(), 2 * sizeof(Fr), hipMemcpyHostToDevice, stream_));
         ZK_HIP(hipStreamSynchronize(stream_));
-        coset_fft_8n(tmp, 2, evals + (size_t)N_SEL * ev_len_);
+        forward(tmp, 2, evals + (size_t)N_SEL * stride);
     }
     Fr one = Fr::one();
     ZK_HIP(hipMemcpyAsync(tmp, &one, sizeof(Fr), hipMemcpyHostToDevice, stream_));
     ZK_HIP(hipStreamSynchronize(stream_));
-    ntt_.transform(NTT_IFFT, tmp, 1, tmp, log_n);
-    coset_fft_8n(tmp, n, evals + (size_t)(N_SEL + 1) * ev_len_);
-    Domain d8 = Domain::make(N8);
+    ntt_.transform(NTT_IFFT, tmp, 1, tmp, log_n_);
+    forward(tmp, n, evals + (size_t)(N_SEL + 1) * stride);
+}
+
+// compute_vanishing_poly_over_coset (domain.rs:256-275): v_h[i] = g^n * w_8n^(n i) - 1, period 8.
+void Prover::build_vanishing() {
+    const uint32_t n = n_;
+    Domain d8 = Domain::make((size_t)8 * n);
     Fr g = Fr::inv(d8.generator_inv);
     Fr gn = Fr::pow_u64(g, n);
     Fr w8 = Fr::pow_u64(d8.group_gen, n);
@@ -222,6 +244,42 @@ void Prover::build_l1_and_vanishing(bool with_linear) {
         vh_inv_[i] = Fr::inv(vh_[i]);
         cur = Fr::mul(cur, w8);
     }
+}
+
+// Which coset the loaded key's proofs evaluate the quotient on.  With the arithmetic and permutation terms only, the
+// numerator has degree at most 5n + 6 and the quotient 4n + 6: its 4n evaluations over g<w_4n> fix it up to its seven
+// top coefficients, and those follow from the top coefficients of the round polynomials (quotient_half_coset).
+void Prover::choose_coset() {
+    half_coset_ = !force_full_ && widgets_ == 0 && !shared() && n_ >= 16;
+    last_half_ = false;
+    if (!half_coset_) {
+        evals4_.release();
+        sel_h_.release();
+    }
+}
+
+// coefficients n+1-j, j < 7, of the sigma polynomials (they have n coefficients: the first two are zero)
+void Prover::read_sigma_tops() {
+    const uint32_t n = n_;
+    Fr buf[4][5];
+    for (int k = 0; k < 4; k++)
+        ZK_HIP(hipMemcpyAsync(buf[k], key_poly(S1 + k) + (n - 5), 5 * sizeof(Fr), hipMemcpyDeviceToHost, stream_));
+    ZK_HIP(hipStreamSynchronize(stream_));
+    for (int k = 0; k < 4; k++) {
+        sigma_top_[k][0] = sigma_top_[k][1] = Fr::zero();
+        for (int j = 2; j < 7; j++) sigma_top_[k][j] = buf[k][4 - (j - 2)];   // coefficient n+1-j = buf index (n+1-j) - (n-5)
+    }
+}
+
+// The 8n vectors of a key that proves over the 4n coset: needed by the 8n quotient (a proof whose numerator does not
+// vanish on the domain, the piecewise entry point) and by to_bytes.  Uses small_ as scratch.
+void Prover::ensure_evals8n() {
+    if (evals8_built_) return;
+    ZK_REQUIRE(loaded(), ZKGPU_ERR_NOT_LOADED, "no prover key loaded");
+    evals_.reserve((size_t)(N_SEL + 2) * ev_len_ * sizeof(Fr));
+    small_.reserve(coset_buffer_bytes());
+    build_key_evals(false, evals_.as<Fr>(), ev_len_, small_.as<Fr>(), true, true);
+    evals8_built_ = true;
 }
 
 // The public-input polynomial is sum_j pi_j L_j (composer.rs:1001-1014 + prover.rs:305-306); its 8n coset evaluations
@@ -235,7 +293,7 @@ void Prover::build_pi_lagrange() {
         if (i < n_) idx.push_back(i);
     std::sort(idx.begin(), idx.end());
     idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
-    const size_t N8 = ev_len_;
+    const size_t N8 = half_coset_ ? (size_t)4 * n_ : ev_len_;   // the coset points this key's proofs evaluate
     if (idx.empty() || idx.size() > 4 || idx.size() * N8 * sizeof(Fr) > (8ull << 30)) return;
     pi_lagrange_.reserve(idx.size() * N8 * sizeof(Fr));
     Fr *tmp = work_.as<Fr>();
@@ -243,7 +301,10 @@ void Prover::build_pi_lagrange() {
     for (size_t j = 0; j < idx.size(); j++) {
         poly_.zero_and_scatter(tmp, n_, &idx[j], &one, 1);
         ntt_.transform(NTT_IFFT, tmp, n_, tmp, log_n_);
-        coset_fft_8n(tmp, n_, pi_lagrange_.as<Fr>() + j * N8);
+        if (half_coset_)
+            coset_fft_4n(tmp, n_, pi_lagrange_.as<Fr>() + j * N8);
+        else
+            coset_fft_8n(tmp, n_, pi_lagrange_.as<Fr>() + j * N8);
     }
     ZK_HIP(hipStreamSynchronize(stream_));
     pi_lagrange_idx_ = idx;
@@ -269,12 +330,10 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
     }
     ev_len_ = N8 / key_world_;
     polys_.reserve((size_t)N_SEL * n * sizeof(Fr));
-    evals_.reserve((size_t)(N_SEL + 2) * ev_len_ * sizeof(Fr));
     sigma_.reserve((size_t)4 * n * sizeof(Fr));
     work_.reserve((size_t)N_SEL * n * sizeof(Fr));
     Fr *stage = work_.as<Fr>();
     Fr *polys = polys_.as<Fr>();
-    Fr *evals = evals_.as<Fr>();
     ZK_HIP(hipMemcpyAsync(stage, selector_evals_host, (size_t)N_SEL * n * sizeof(Fr), hipMemcpyHostToDevice, stream_));
     ZK_HIP(hipMemcpyAsync(sigma_.p, stage + (size_t)S1 * n, (size_t)4 * n * sizeof(Fr), hipMemcpyDeviceToDevice, stream_));
     n_ = n;
@@ -288,14 +347,26 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
         // compiler.rs:123-147 (selectors) and permutation.rs:164-171 (sigmas): ifft, leading zeros dropped
         ntt_.transform(NTT_IFFT, stage + (size_t)k * n, n, polys + (size_t)k * n, log_n);
         poly_len_[k] = poly_.length_without_leading_zeros(polys + (size_t)k * n, n);
-        // compiler.rs:241-301: coset_fft over the 8n domain
-        coset_fft_8n(polys + (size_t)k * n, poly_len_[k], evals + (size_t)k * ev_len_);
     }
     if (poly_len_[Q_RANGE]) widgets_ |= 1u;
     if (poly_len_[Q_LOGIC]) widgets_ |= 2u;
     if (poly_len_[Q_FIXED]) widgets_ |= 4u;
     if (poly_len_[Q_VAR]) widgets_ |= 8u;
-    build_l1_and_vanishing(true);
+    choose_coset();
+    if (half_coset_) {
+        // the selector values on the domain itself stay for the row-wise gate check of every proof
+        sel_h_.reserve((size_t)7 * n * sizeof(Fr));
+        ZK_HIP(hipMemcpyAsync(sel_h_.p, stage, (size_t)7 * n * sizeof(Fr), hipMemcpyDeviceToDevice, stream_));
+        evals4_.reserve((size_t)(N_SEL + 2) * 4 * n * sizeof(Fr));
+        build_key_evals(true, evals4_.as<Fr>(), (size_t)4 * n, stage, true, true);
+        read_sigma_tops();
+        evals8_built_ = false;
+    } else {
+        evals_.reserve((size_t)(N_SEL + 2) * ev_len_ * sizeof(Fr));
+        build_key_evals(false, evals_.as<Fr>(), ev_len_, stage, true, true);
+        evals8_built_ = true;
+    }
+    build_vanishing();
     // compiler.rs:152-171: selector commitments default to the identity on error, sigma commitments must succeed
     for (int k = 0; k < N_SEL; k++) {
         int rc = commit_dev(polys + (size_t)k * n, poly_len_[k], sel_comms_[k]);
@@ -499,7 +570,20 @@ void Prover::load_key_bytes(const uint8_t *b, size_t len, const uint64_t *pi_ind
     // (composer/permutation.rs:189-199)
     for (int k = 0; k < 4; k++)
         ntt_.transform(NTT_FFT, polys + (size_t)(S1 + k) * n, poly_len_[S1 + k], sigma_.as<Fr>() + (size_t)k * n, log_n);
-    build_l1_and_vanishing(false);
+    // L1 on the coset is not part of the serialized key (quotient_poly.rs:237-245 rebuilds it per proof)
+    build_key_evals(false, evals, N8, stage, false, false);
+    evals8_built_ = true;
+    build_vanishing();
+    choose_coset();
+    if (half_coset_) {
+        // the 4n coset is every second point of the 8n coset: the stored vectors' even entries
+        evals4_.reserve((size_t)(N_SEL + 2) * 4 * n * sizeof(Fr));
+        for (int k = 0; k < N_SEL + 2; k++) poly_.take_even(evals + (size_t)k * N8, (size_t)4 * n, evals4_.as<Fr>() + (size_t)k * 4 * n);
+        sel_h_.reserve((size_t)7 * n * sizeof(Fr));
+        for (int k = 0; k < 7; k++)
+            ntt_.transform(NTT_FFT, polys + (size_t)k * n, poly_len_[k], sel_h_.as<Fr>() + (size_t)k * n, log_n);
+        read_sigma_tops();
+    }
     // v_h_coset_8n has period 8 (domain.rs:256-275); the stored vector must be the one of this domain
     for (int i = 0; i < 8; i++) {
         Fr raw;
@@ -520,6 +604,7 @@ size_t Prover::to_bytes(uint8_t *out, size_t cap) {
     const uint32_t n = n_;
     const size_t N8 = (size_t)8 * n;
     const size_t eval_size = DOMAIN_BYTES + N8 * 32;
+    if (out != nullptr) ensure_evals8n();
     // ProverKey::serialization_size (widget.rs:265-278): every polynomial is budgeted at q_m's length
     const size_t pk_size = (size_t)poly_len_[Q_M] * 32 * 15 + eval_size * 17 + 8 * 17;
     const size_t ck_size = msm_.raw_size(), vk_size = 8 + 48 * N_SEL;
@@ -630,6 +715,9 @@ void Prover::blind_poly(const Fr *evals_dev, int hiding_degree, const Fr *blinde
 uint64_t Prover::quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4], const uint64_t wire_len[4], const Fr *pi,
                           uint64_t pi_len, const Fr ch[7], Fr *t_out, const Fr *pi_values) {
     ZK_REQUIRE(loaded(), ZKGPU_ERR_NOT_LOADED, "quotient: no prover key loaded");
+    const uint32_t ready = ev_ready_;   // ensure_evals8n may use the coset buffer as scratch: only on a path that set no mark
+    ev_ready_ = 0;
+    ensure_evals8n();
     const size_t N8 = (size_t)8 * n_, L = ev_len_;   // L = the coset points this context evaluates
     ZK_REQUIRE(!shared() || (coll_.usable() && coll_.world == key_world_ && coll_.rank == key_rank_), ZKGPU_ERR_INVALID_ARG,
                "quotient: the key was loaded for another set of ranks than set_collective names now");
@@ -638,15 +726,14 @@ uint64_t Prover::quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4],
     const uint32_t lg8 = log_n_ + 3;
     // quotient_poly.rs:46-51,120; prove() may have launched some of these transforms already, while it waited for a
     // commitment
-    const uint32_t ready = ev_ready_;
-    ev_ready_ = 0;
     if (!(ready & 1u)) coset_fft_8n(z, z_len, ev);
     if (!(ready & 2u))
         for (int k = 0; k < 4; k++) coset_fft_8n(wires[k], wire_len[k], ev + (size_t)(k + 1) * L);
     if (pi != nullptr) {
         coset_fft_8n(pi, pi_len, ev + 5 * L);
     } else {
-        ZK_REQUIRE(pi_values != nullptr && !pi_lagrange_idx_.empty(), ZKGPU_ERR_INTERNAL, "quotient: no public-input vectors");
+        ZK_REQUIRE(pi_values != nullptr && !pi_lagrange_idx_.empty() && !half_coset_, ZKGPU_ERR_INTERNAL,
+                   "quotient: no public-input vectors over the 8n coset");
         LinArgs lin;
         lin.n_terms = (int)pi_lagrange_idx_.size();
         for (int j = 0; j < lin.n_terms; j++) {
@@ -666,9 +753,15 @@ uint64_t Prover::quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4],
     q.c = ev + 3 * L;
     q.d = ev + 4 * L;
     q.pi = ev + 5 * L;
-    for (int k = 0; k < N_SEL; k++) q.sel[k] = key_eval8n(k);
-    q.linear = key_eval8n(N_SEL);
-    q.l1 = key_eval8n(N_SEL + 1);
+    for (int k = 0; k < N_SEL + 2; k++) {
+        const Fr *v = evals_.as<Fr>() + (size_t)k * ev_len_;
+        if (k < N_SEL)
+            q.sel[k] = v;
+        else if (k == N_SEL)
+            q.linear = v;
+        else
+            q.l1 = v;
+    }
     q.out = shared() ? ev + 6 * L : t_out;
     q.alpha = ch[0];
     q.alpha_sq = Fr::sqr(ch[0]);
@@ -692,6 +785,120 @@ uint64_t Prover::quotient(const Fr *z, uint64_t z_len, const Fr *const wires[4],
     else
         ntt_.transform(NTT_COSET_IFFT, t_out, N8, t_out, lg8);
     return poly_.length_without_leading_zeros(t_out, N8);    // Polynomial::from_coefficients_vec
+}
+
+// a <- a * f modulo Y^7
+static void series_mul7(Fr a[7], const Fr f[7]) {
+    Fr out[7];
+    for (int m = 0; m < 7; m++) {
+        Fr acc = Fr::zero();
+        for (int j = 0; j <= m; j++) acc = Fr::add(acc, Fr::mul(a[j], f[m - j]));
+        out[m] = acc;
+    }
+    for (int m = 0; m < 7; m++) a[m] = out[m];
+}
+
+// build_quotient_polynomial (quotient_poly.rs:15-100) for a key with the arithmetic and permutation terms only, for round
+// polynomials of the lengths prove() produces (wires n + 2, z n + 3) whose numerator is known to vanish on the domain.
+// The numerator N has degree at most 5n + 6, so t = N / Z_H has at most 4n + 7 coefficients.  The pointwise identity is
+// evaluated on the 4n points g w_4n^k -- every second point of the reference's 8n coset, so the same kernel runs with
+// the slice parameters (first 0, step 2) and the "next row" four places on -- and the inverse coset transform returns
+// t modulo X^4n - g^4n, i.e. r_i = t_i + g^4n t_(4n+i) for i < 7 and t_i elsewhere.  The seven top coefficients are
+// those of N, t_(4n+i) = N_(5n+i), and only alpha (z prod_w (w + beta k_w X + gamma) - z(wX) prod_w (w + beta sigma_w +
+// gamma)) reaches those degrees: they are products of the seven top coefficients of each factor, which the host holds
+// in tops_host_ (wires: coefficients n-5 .. n+1, z: n-4 .. n+2, gathered right after blinding).  Every value equals the
+// reference's: both are the coefficients of the one polynomial t.
+uint64_t Prover::quotient_half_coset(const Fr *z, const Fr *const wires[4], const Fr ch[7], const Fr *pi_values, const Fr *pi_poly,
+                                     Fr *t_out) {
+    const size_t n = n_, L = 4 * n;
+    Fr *ev = small_.as<Fr>();
+    const uint32_t ready = ev_ready_;
+    ev_ready_ = 0;
+    if (!(ready & 1u)) coset_fft_4n(z, n + 3, ev);
+    if (!(ready & 2u))
+        for (int k = 0; k < 4; k++) coset_fft_4n(wires[k], n + 2, ev + (size_t)(k + 1) * L);
+    if (pi_values == nullptr) {
+        coset_fft_4n(pi_poly, n, ev + 5 * L);
+    } else {
+        // sum_j pi_j L_j over the resident Lagrange vectors (build_pi_lagrange)
+        LinArgs lin;
+        lin.n_terms = (int)pi_lagrange_idx_.size();
+        for (int j = 0; j < lin.n_terms; j++) {
+            lin.t[j].coeffs = pi_lagrange_.as<Fr>() + (size_t)j * L;
+            lin.t[j].len = L;
+            lin.t[j].scalar = pi_values[j];
+        }
+        lin.constant = Fr::zero();
+        lin.out = ev + 5 * L;
+        lin.out_len = L;
+        poly_.linear_combination(lin);
+    }
+    QuotientArgs q;
+    q.z = ev;
+    q.a = ev + L;
+    q.b = ev + 2 * L;
+    q.c = ev + 3 * L;
+    q.d = ev + 4 * L;
+    q.pi = ev + 5 * L;
+    const Fr *key = evals4_.as<Fr>();
+    for (int k = 0; k < N_SEL; k++) q.sel[k] = key + (size_t)k * L;
+    q.linear = key + (size_t)N_SEL * L;
+    q.l1 = key + (size_t)(N_SEL + 1) * L;
+    q.out = t_out;
+    q.alpha = ch[0];
+    q.alpha_sq = Fr::sqr(ch[0]);
+    q.beta = ch[1];
+    q.gamma = ch[2];
+    q.range_ch = ch[3];
+    q.logic_ch = ch[4];
+    q.fixed_ch = ch[5];
+    q.var_ch = ch[6];
+    for (int i = 0; i < 8; i++) q.vh_inv[i] = vh_inv_[i];
+    q.n8 = (uint32_t)L;
+    q.world = 2;
+    q.first = 0;
+    q.rot = 4;
+    q.widgets = 0;
+    poly_.quotient(q);
+    ntt_.transform(NTT_COSET_IFFT, t_out, L, t_out, log_n_ + 2);
+
+    // the seven top coefficients, as power series in Y = 1/X truncated at Y^7: entry j belongs to the factor's degree
+    // bound minus j
+    const Fr &alpha = ch[0], &beta = ch[1];
+    const Fr *win = tops_host_;
+    Fr id[7], cp[7], f[7];
+    const Domain dn = Domain::make(n);
+    {
+        // z(wX) has the coefficients z_j w^j, and w^n = 1: coefficient n+2-j carries w^(2-j)
+        Fr pw = Fr::sqr(dn.group_gen);
+        for (int j = 0; j < 7; j++) {
+            id[j] = win[29 + 6 - j];
+            cp[j] = Fr::mul(id[j], pw);
+            pw = Fr::mul(pw, dn.group_gen_inv);
+        }
+    }
+    for (int k = 0; k < 4; k++) {
+        for (int j = 0; j < 7; j++) f[j] = win[7 * k + 6 - j];   // beta k_w X + gamma lies below degree n - 5
+        series_mul7(id, f);
+        for (int j = 0; j < 7; j++) f[j] = Fr::add(f[j], Fr::mul(beta, sigma_top_[k][j]));
+        series_mul7(cp, f);
+    }
+    const Domain d8 = Domain::make(8 * n);
+    const Fr g4n = Fr::pow_u64(Fr::inv(d8.generator_inv), L);
+    uint64_t idx[7];
+    Fr hi[7], lo[7];
+    bool sub[7], set[7];
+    for (int i = 0; i < 7; i++) {
+        hi[i] = Fr::mul(alpha, Fr::sub(id[6 - i], cp[6 - i]));   // t_(4n+i) = N_(5n+i): entry j = 6 - i
+        lo[i] = Fr::mul(g4n, hi[i]);
+        idx[i] = (uint64_t)i;
+        sub[i] = true;
+        set[i] = false;
+    }
+    poly_.patch(t_out, idx, lo, sub, 7);            // t_i = r_i - g^4n t_(4n+i)
+    for (int i = 0; i < 7; i++) idx[i] = L + i;
+    poly_.patch(t_out, idx, hi, set, 7);
+    return poly_.length_without_leading_zeros(t_out, L + 7);    // Polynomial::from_coefficients_vec
 }
 
 // proof_system/proof.rs:511-561
@@ -871,12 +1078,44 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     }
     for (auto &pi : public_inputs) tr.append_scalar("pi", pi);  // prover.rs:236-238
 
+    // composer.rs:1001-1014: the dense public inputs, built on the device from the few (index, value) pairs; a later
+    // pair with the same index overrides an earlier one, as the reference's sequential writes do.
+    std::map<uint64_t, Fr> pi_last;
+    for (size_t i = 0; i < pi_indexes_.size() && i < n_pi; i++)
+        if (pi_indexes_[i] < n) pi_last[pi_indexes_[i]] = public_inputs[i];
+    {
+        std::vector<uint64_t> idx;
+        std::vector<Fr> vals;
+        for (auto &kv : pi_last) {
+            idx.push_back(kv.first);
+            vals.push_back(kv.second);
+        }
+        poly_.zero_and_scatter(p_pi, n, idx.data(), vals.data(), (uint32_t)idx.size());
+    }
+
     // protocol phase 1: wire polynomials (prover.rs:240-269)
     // hipMemcpyDefault: the caller's pointer may be host memory or already resident in HBM
     ZK_HIP(hipMemcpyAsync(wires, wires_host, 4 * n * sizeof(Fr), hipMemcpyDefault, stream_));
     Fr *wp[4] = {p_a, p_b, p_c, p_d};
     for (int k = 0; k < 4; k++) blind_poly(wires + k * n, 1, bl + 2 * k, wp[k]);
     int rc;
+    // A key that proves over the 4n coset: the quotient may take that route only if its numerator vanishes on the
+    // domain, i.e. every row satisfies its gate (checked here, the flag arrives with the wire commitments) and the
+    // permutation accumulator closes (known when it is built).  Otherwise the proof runs over the 8n coset like the
+    // reference, garbage quotient and degree error included.
+    const uint32_t FLAG_AT = 28, Z_AT = 29, TOPS = 36;   // tops_host_: 4 wire windows, the flag, z's window
+    if (half_coset_) {
+        tops_dev_.reserve(TOPS * sizeof(Fr));
+        if (!tops_host_) ZK_HIP(hipHostMalloc(reinterpret_cast<void **>(&tops_host_), TOPS * sizeof(Fr), hipHostMallocDefault));
+        Fr *td = tops_dev_.as<Fr>();
+        ZK_HIP(hipMemsetAsync(td + FLAG_AT, 0, sizeof(Fr), stream_));
+        poly_.gate_check(wires, sel_h_.as<Fr>(), p_pi, (uint32_t)n, reinterpret_cast<uint32_t *>(td + FLAG_AT));
+        const Fr *src[4] = {p_a, p_b, p_c, p_d};
+        const uint64_t first[4] = {n - 5, n - 5, n - 5, n - 5};
+        poly_.gather_windows(4, src, first, 7, td);
+        ZK_HIP(hipMemcpyAsync(tops_host_, td, (FLAG_AT + 1) * sizeof(Fr), hipMemcpyDeviceToHost, stream_));
+    }
+    last_half_ = false;
     // The coset evaluations the quotient needs of a polynomial depend on no challenge: they are launched right behind
     // the polynomial's commitment and run while the host adds up the commitment and feeds the transcript.
     ev_ready_ = 0;
@@ -890,11 +1129,18 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
         const Fr *cp[4] = {p_a, p_b, p_c, p_d};
         const uint64_t cl[4] = {n + 2, n + 2, n + 2, n + 2};
         rc = commit_many(4, cp, cl, &out.comms[0], [&] {
-            for (int k = 0; k < 4; k++) coset_fft_8n(wp[k], n + 2, coset_ev + (size_t)(k + 1) * ev_len_);
+            // (over the 4n coset on the expectation that the checks pass)
+            for (int k = 0; k < 4; k++) {
+                if (half_coset_)
+                    coset_fft_4n(wp[k], n + 2, coset_ev + (size_t)(k + 1) * 4 * n);
+                else
+                    coset_fft_8n(wp[k], n + 2, coset_ev + (size_t)(k + 1) * ev_len_);
+            }
             ev_ready_ |= 2u;
         });
         if (rc) return rc;
     }
+    bool half = half_coset_ && *reinterpret_cast<const volatile uint32_t *>(tops_host_ + FLAG_AT) == 0;
     tr.append_commitment("a_comm", out.comms[0]);
     tr.append_commitment("b_comm", out.comms[1]);
     tr.append_commitment("c_comm", out.comms[2]);
@@ -908,15 +1154,31 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     {
         const Fr *wv[4] = {wires, wires + n, wires + 2 * n, wires + 3 * n};
         const Fr *sv[4] = {sigma_.as<Fr>(), sigma_.as<Fr>() + n, sigma_.as<Fr>() + 2 * n, sigma_.as<Fr>() + 3 * n};
-        poly_.permutation_z(wv, sv, beta, gamma, ntt_.roots_half(log_n_), (uint32_t)n, z_evals);
+        bool closed = false;
+        poly_.permutation_z(wv, sv, beta, gamma, ntt_.roots_half(log_n_), (uint32_t)n, z_evals, &closed);
+        half = half && closed;
     }
     blind_poly(z_evals, 2, bl + 8, p_z);
+    if (half) {
+        Fr *td = tops_dev_.as<Fr>();
+        const Fr *src[1] = {p_z};
+        const uint64_t first[1] = {n - 4};
+        poly_.gather_windows(1, src, first, 7, td + Z_AT);
+        ZK_HIP(hipMemcpyAsync(tops_host_ + Z_AT, td + Z_AT, 7 * sizeof(Fr), hipMemcpyDeviceToHost, stream_));
+    } else if (half_coset_) {
+        ev_ready_ = 0;   // the wires' evaluations over the 4n coset are of no use to the 8n quotient
+    }
     {
         const Fr *cp[1] = {p_z};
         const uint64_t cl[1] = {n + 3};
         rc = commit_many(1, cp, cl, &out.comms[4], [&] {
-            coset_fft_8n(p_z, n + 3, coset_ev);
-            ev_ready_ |= 1u;
+            if (half) {
+                coset_fft_4n(p_z, n + 3, coset_ev);
+                ev_ready_ |= 1u;
+            } else if (!half_coset_) {
+                coset_fft_8n(p_z, n + 3, coset_ev);
+                ev_ready_ |= 1u;
+            }
         });
         if (rc) return rc;
     }
@@ -930,35 +1192,25 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     const Fr fixed_ch = tr.challenge_scalar("fixed base separation challenge");
     const Fr var_ch = tr.challenge_scalar("variable base separation challenge");
     std::vector<Fr> pi_resident;
-    {
-        // composer.rs:1001-1014 dense public inputs, then ifft (prover.rs:305-306)
-        // The dense vector is built on the device from the few (index, value) pairs; a later pair with the same index
-        // overrides an earlier one, as the reference's sequential writes do.
-        std::map<uint64_t, Fr> last;
-        for (size_t i = 0; i < pi_indexes_.size() && i < n_pi; i++)
-            if (pi_indexes_[i] < n) last[pi_indexes_[i]] = public_inputs[i];
-        std::vector<uint64_t> idx;
-        std::vector<Fr> vals;
-        for (auto &kv : last) {
-            idx.push_back(kv.first);
-            vals.push_back(kv.second);
+    // the resident Lagrange vectors lie over the coset the key proves on: a proof that fell back to the 8n coset
+    // transforms its public-input polynomial
+    if (!pi_lagrange_idx_.empty() && half == half_coset_) {
+        // the values in the order of the resident Lagrange vectors; positions this proof leaves out are zero
+        pi_resident.assign(pi_lagrange_idx_.size(), Fr::zero());
+        for (size_t j = 0; j < pi_lagrange_idx_.size(); j++) {
+            auto it = pi_last.find(pi_lagrange_idx_[j]);
+            if (it != pi_last.end()) pi_resident[j] = it->second;
         }
-        if (!pi_lagrange_idx_.empty()) {
-            // the values in the order of the resident Lagrange vectors; positions this proof leaves out are zero
-            pi_resident.assign(pi_lagrange_idx_.size(), Fr::zero());
-            for (size_t j = 0; j < pi_lagrange_idx_.size(); j++) {
-                auto it = last.find(pi_lagrange_idx_[j]);
-                if (it != last.end()) pi_resident[j] = it->second;
-            }
-        } else {
-            poly_.zero_and_scatter(p_pi, n, idx.data(), vals.data(), (uint32_t)idx.size());
-            ntt_.transform(NTT_IFFT, p_pi, n, p_pi, log_n_);
-        }
+    } else {
+        ntt_.transform(NTT_IFFT, p_pi, n, p_pi, log_n_);   // prover.rs:305-306
     }
     const Fr ch7[7] = {alpha, beta, gamma, range_ch, logic_ch, fixed_ch, var_ch};
     const uint64_t wl[4] = {n + 2, n + 2, n + 2, n + 2};
-    const uint64_t t_len = pi_resident.empty() ? quotient(p_z, n + 3, wp, wl, p_pi, n, ch7, t)
-                                               : quotient(p_z, n + 3, wp, wl, nullptr, 0, ch7, t, pi_resident.data());
+    const uint64_t t_len = half ? quotient_half_coset(p_z, wp, ch7, pi_resident.empty() ? nullptr : pi_resident.data(), p_pi, t)
+                           : pi_resident.empty() ? quotient(p_z, n + 3, wp, wl, p_pi, n, ch7, t)
+                                                 : quotient(p_z, n + 3, wp, wl, nullptr, 0, ch7, t, pi_resident.data());
+    last_half_ = half;
+    proved_once_ = true;
     lap(2, t_phase);
     // prover.rs:327-351: the reference slices t[3n..] and indexes t_fourth[0]; both panic when t is shorter
     if (t_len < 3 * n + 1) return ZKGPU_ERR_QUOTIENT_SHAPE;

@@ -64,7 +64,19 @@ class Prover {
     const AffineOut *selector_comms() const { return sel_comms_; }
     // device pointers to the key (for the piecewise entry points and tests)
     const Fr *key_poly(int k) const { return reinterpret_cast<const Fr *>(polys_.p) + (size_t)k * n_; }
-    const Fr *key_eval8n(int k) const;  // k < N_SEL selectors, N_SEL linear evaluations, N_SEL + 1 L1
+    // k < N_SEL selectors, N_SEL linear evaluations, N_SEL + 1 L1.  A key that proves over the 4n coset (see
+    // half_coset()) builds its 8n vectors at the first call that needs them and keeps them from then on.
+    const Fr *key_eval8n(int k);
+    // True when proofs of the loaded key evaluate the quotient's numerator on the 4n-point coset g<w_4n> (every second
+    // point of the reference's 8n coset) instead of all 8n points: keys whose range, logic and curve selectors are
+    // identically zero, held by one context, n >= 16.  See Prover::quotient_half_coset.
+    bool half_coset() const { return half_coset_; }
+    // which of the two the most recent prove() took (false after a proof that fell back to the 8n coset)
+    bool last_proof_half_coset() const { return last_half_; }
+    bool proved_once() const { return proved_once_; }
+    // on = true: keys loaded from now on prove over the full 8n coset whatever their gates (the reference's own route;
+    // measurements and tests compare the two)
+    void force_full_coset(bool on) { force_full_ = on; }
 
     // build_quotient_polynomial (quotient_poly.rs:15-100) on device polynomials; t_out must hold 8n elements.
     // Returns the coefficient count after truncating leading zeros.
@@ -97,8 +109,17 @@ class Prover {
     int commit_many(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, AffineOut *out,
                     const std::function<void()> &meanwhile = nullptr);
     void blind_poly(const Fr *evals_dev, int hiding_degree, const Fr *blinders, Fr *out_dev);
-    void build_l1_and_vanishing(bool with_linear);
+    void build_vanishing();
+    // coset evaluations of the 15 key polynomials, of X and of L1 into evals[k * stride]: over the 4n coset (half) or as
+    // coset_fft_8n does it; tmp holds at least n elements
+    void build_key_evals(bool half, Fr *evals, size_t stride, Fr *tmp, bool with_selectors, bool with_linear);
+    void ensure_evals8n();
+    void choose_coset();
+    void read_sigma_tops();
     void build_pi_lagrange();
+    void coset_fft_4n(const Fr *coeffs, uint64_t len, Fr *out);
+    uint64_t quotient_half_coset(const Fr *z, const Fr *const wires[4], const Fr ch7[7], const Fr *pi_values, const Fr *pi_poly,
+                                 Fr *t_out);
     // coset_fft over the 8n domain (fft/domain.rs:176-185) of a polynomial held in full: all 8n evaluations, or this
     // context's cyclic slice of them when the key was loaded under set_collective
     void coset_fft_8n(const Fr *coeffs, uint64_t len, Fr *out);
@@ -135,7 +156,15 @@ class Prover {
     hipEvent_t sums_ready_ = nullptr;   // behind the copy of a commitment's group sums
     // coset evaluations prove() has already launched into small_ for the coming quotient(): bit 0 z, bit 1 the wires
     uint32_t ev_ready_ = 0;
-    DevBuf pi_lagrange_;                  // for keys with few public inputs: L_j on the 8n coset, one vector per position
+    // Proving over the 4n coset
+    bool half_coset_ = false, last_half_ = false, force_full_ = false, proved_once_ = false;
+    bool evals8_built_ = false;   // evals_ holds the 8n vectors (always true for keys that do not use the 4n coset)
+    DevBuf evals4_;               // (N_SEL + 2) x 4n: the key's vectors over the 4n coset
+    DevBuf sel_h_;                // 7 x n: q_m q_l q_r q_o q_4 q_c q_arith on the domain itself (the row-wise gate check)
+    DevBuf tops_dev_;             // gathered top coefficients + the gate check's flag, copied to tops_host_ in one piece
+    Fr *tops_host_ = nullptr;     // pinned: 5 windows of 7 coefficients, then the flag word
+    Fr sigma_top_[4][7];          // coefficients n+1-j (j < 7) of the four sigma polynomials
+    DevBuf pi_lagrange_;                  // for keys with few public inputs: L_j on the coset the key proves over, one vector per position
     std::vector<uint64_t> pi_lagrange_idx_;   // the distinct positions, ascending; empty = not resident
 };
 

@@ -452,18 +452,21 @@ def tiled_srs(n_points):
     return np.tile(base, (reps, 1))[:n_points]
 
 
-def quotient_roofline(ctx, n, widgets=False):
-    """quotient_limb_kernel (arithmetic-only circuits) of the most recent proof on `ctx`: one thread per point of the 8n coset."""
+def quotient_roofline(ctx, n, coset=8):
+    """quotient_limb_kernel (arithmetic-only circuits) of the most recent proof on `ctx`: one thread per point of the
+    coset the proof ran over (`coset` x n points: 4n for keys with the arithmetic and permutation terms only, the
+    reference's 8n otherwise)."""
     ms = ctx.quotient_kernel_ms()
     streams = 19       # a b c d z | q_m q_l q_r q_o q_f q_c q_arith | sigma 1-4 | X, L1 and PI on the coset
-    alg = 8.0 * n * 32 * (streams + 1)
+    points = float(coset) * n
+    alg = points * 32 * (streams + 1)
     products = 25      # 7 arithmetic gate, 17 permutation argument (beta X twice: plain and times 32), 1 for 1 / Z_H
-    mad_rate = 8.0 * n * products * FR_MADS / 64 / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "quotient_limb_kernel (8n = %d points, %d streams read, 1 written)" % (8 * n, streams),
+    mad_rate = points * products * FR_MADS / 64 / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "quotient_limb_kernel (%dn = %d points, %d streams read, 1 written)" % (coset, int(points), streams),
             "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
             "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(PROFILE_ROUND + "_pmc_prove.csv", "quotient_limb_kernel"),
+            "traffic": pmc_traffic(PROFILE_ROUND + ("_pmc_prove.csv" if coset == 4 else "_pmc_prove_8n.csv"), "quotient_limb_kernel"),
             "valu": {"unit": "G v_mad_u64_u32 wave-instructions/s", "achieved": round(mad_rate, 1), "peak": MAD_PEAK_G,
                      "frac": round(mad_rate / MAD_PEAK_G, 3), "field_products_per_point": products}}
 
@@ -486,6 +489,8 @@ def run_prove(args, rank, world, local, device):
     else:
         if args.msm_window or args.msm_segment:
             ctx.msm_set_params(args.msm_window, args.msm_segment)
+        if args.full_coset:
+            ctx.force_full_coset(True)
         ctx.srs_setup(circuits.seeded_tau(), circuits.g1_generator_limbs(), n + 7)   # tau^i * G, generated on the device
     ctx.sync()
     t_srs = time.perf_counter() - t0
@@ -520,7 +525,10 @@ def run_prove(args, rank, world, local, device):
                              "commitments and count into the first two laps")
         out["setup_s"] = {"srs_gpu": round(t_srs, 3), "circuit_host": round(t_circ, 2), "key_preprocess_gpu": round(t_key, 3)}
         out["proof_digest"] = {"a_comm_x0": hex(int(proof["comms"][0][0])), "z_eval_0": hex(int(proof["evals"][14][0]))}
-        quot = quotient_roofline(ctx, n)
+        out["quotient_coset"] = ("%dn points" % timed["coset"]) + (
+            " (every second point of the reference's 8n coset; the seven top coefficients of the quotient restored from "
+            "those of the round polynomials: the same coefficients)" if timed["coset"] == 4 else " (the reference's coset)")
+        quot = quotient_roofline(ctx, n, timed["coset"])
         # dominant kernel: msm_accumulate_kernel of the 11 commitments; HIP events on the library's stream around the
         # phases of one n-point commitment
         n_local = count if sharded else n      # points this GPU holds
@@ -707,6 +715,8 @@ def main():
                     help="time the CPU oracle on the full 2^log-gates proof (minutes) instead of the bounded sample")
     ap.add_argument("--no-sub-records", action="store_true",
                     help="prove workload: leave out the msm / ntt / msm_scaling / sharded_prove records")
+    ap.add_argument("--full-coset", action="store_true",
+                    help="prove workload: evaluate the quotient over the reference's 8n coset even where 4n points suffice")
     ap.add_argument("--msm-window", type=int, default=0, help="tuning: force the MSM window width (0 = the engine's choice)")
     ap.add_argument("--msm-segment", type=int, default=0, help="tuning: log2 of the buckets per reduction segment (0 = default)")
     args = ap.parse_args()
@@ -724,8 +734,8 @@ def main():
         value, elapsed, extra, ctx = run_prove(args, rank, world, local, device)
         line = {"metric": "PLONK prove @2^%d gates" % args.log_gates, "unit": "proofs/s", "scaling": "weak",
                 "dtype": "u32x8 Fr / u32x12 Fq (Montgomery)",
-                "config": {"workload": "full PLONK prove, 2^%d gates (wire commits, permutation Z, quotient over the 8n "
-                                       "coset, linearization, openings), bit-exact vs the CPU prover" % args.log_gates,
+                "config": {"workload": "full PLONK prove, 2^%d gates (wire commits, permutation Z, quotient, "
+                                       "linearization, openings), bit-exact vs the CPU prover" % args.log_gates,
                            "n": 1 << args.log_gates, "parallelism": "independent proofs per GPU"}}
         if args.sharded and world > 1:
             line["scaling"] = "strong"

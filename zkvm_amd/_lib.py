@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkgpu.so")
+# ZKGPU_LIB names another build of the library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("ZKGPU_LIB") or os.path.join(_HERE, "libzkgpu.so")
 
 ERRORS = {
     -1: "ZKGPU_ERR_INVALID_ARG", -2: "ZKGPU_ERR_HIP", -3: "ZKGPU_ERR_NO_DEVICE", -4: "ZKGPU_ERR_DOMAIN_SIZE",

@@ -19,6 +19,7 @@
 // butterfly stages run per LDS round trip (a thread carries four rows in registers), and the tables hold the
 // twiddles in the same limb form, ready to multiply by; the kernel is bound by integer VALU issue, not by memory.
 #include "ntt.hpp"
+#include <mutex>
 #include "fr9.cuh"
 
 namespace zk {
@@ -42,7 +43,6 @@ static Fr coset_generator() {
 static const uint32_t TWO_ADACITY = 32;  // scalar.rs:187
 
 Domain Domain::make(uint64_t num_coeffs) {
-    Domain d;
     uint64_t s = 1;
     uint32_t lg = 0;
     while (s < num_coeffs) {
@@ -50,6 +50,16 @@ Domain Domain::make(uint64_t num_coeffs) {
         lg++;
     }
     ZK_REQUIRE(lg < TWO_ADACITY, ZKGPU_ERR_DOMAIN_SIZE, "InvalidEvalDomainSize: log2(size) must be below 32");
+    // three field inversions stand behind a domain; a proof asks for the same two or three domains several times
+    static Domain cache[TWO_ADACITY];
+    static std::once_flag built[TWO_ADACITY];
+    std::call_once(built[lg], [&] { cache[lg] = compute(lg); });
+    return cache[lg];
+}
+
+Domain Domain::compute(uint32_t lg) {
+    Domain d;
+    const uint64_t s = 1ull << lg;
     d.size = s;
     d.log_size = lg;
     d.group_gen = root_of_unity_2_32();

@@ -15,6 +15,7 @@ struct Domain {
     Fr size_as_field_element, size_inv, group_gen, group_gen_inv, generator_inv;
     // domain.rs:106-133; throws ZKGPU_ERR_DOMAIN_SIZE when log2(size) >= 32 (TWO_ADACITY)
     static Domain make(uint64_t num_coeffs);
+    static Domain compute(uint32_t log_size);   // what make() keeps one copy of per size
 };
 
 enum NttMode { NTT_FFT = 0, NTT_IFFT = 1, NTT_COSET_FFT = 2, NTT_COSET_IFFT = 3 };

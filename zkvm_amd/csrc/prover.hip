@@ -34,6 +34,7 @@ static Fr fr_u64(uint64_t x) {
 struct PlonkTranscript {
     MerlinTranscript t;
     explicit PlonkTranscript(const std::string &label) : t(label) {}
+    explicit PlonkTranscript(const MerlinTranscript &from) : t(from) {}
     void append_commitment(const char *label, const AffineOut &c) {
         uint64_t xy[12];
         uint8_t out[48];
@@ -317,6 +318,7 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
     ZK_REQUIRE(msm_.n_points() > 0, ZKGPU_ERR_NOT_LOADED, "prover_key_load: load the SRS first");
     ZK_REQUIRE((uint64_t)n * 8 < (1ull << 32), ZKGPU_ERR_DOMAIN_SIZE, "InvalidEvalDomainSize: 8n must be below 2^32");
     n_ = 0;
+    seed_tr_.reset();
     uint32_t log_n = 0;
     while ((1u << log_n) < n) log_n++;
     const size_t N8 = (size_t)8 * n;
@@ -526,6 +528,7 @@ void Prover::load_key_bytes(const uint8_t *b, size_t len, const uint64_t *pi_ind
 
     // CommitKey::from_slice_unchecked (kzg10/key.rs:54-66)
     n_ = 0;
+    seed_tr_.reset();
     key_world_ = 1;
     key_rank_ = 0;
     ev_len_ = N8;
@@ -1062,10 +1065,12 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     Fr *r_poly = t_high + cap, *agg = r_poly + lin_cap, *wit = agg + lin_cap;
     Fr *ev_dev = wit + lin_cap;
 
-    // transcript.rs:51-65 + widget.rs:199-228 (seed_transcript; "s_sigma_4" carries s_sigma_1, as in the reference)
-    PlonkTranscript tr(label_);
-    tr.circuit_domain_sep(constraints_);
-    {
+    // transcript.rs:51-65 + widget.rs:199-228 (seed_transcript; "s_sigma_4" carries s_sigma_1, as in the reference).
+    // The seeded transcript depends on the key only: it is built once and every proof starts from a copy
+    // (prover.rs:226: self.transcript.clone()).
+    if (!seed_tr_) {
+        PlonkTranscript seed(label_);
+        seed.circuit_domain_sep(constraints_);
         static const struct {
             const char *label;
             int sel;
@@ -1073,9 +1078,11 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
                      {"q_c", Q_C},         {"q_f", Q_F},         {"q_arith", Q_ARITH}, {"q_range", Q_RANGE},
                      {"q_logic", Q_LOGIC}, {"q_variable_group_add", Q_VAR}, {"q_fixed_group_add", Q_FIXED},
                      {"s_sigma_1", S1},    {"s_sigma_2", S2},    {"s_sigma_3", S3}, {"s_sigma_4", S1}};
-        for (auto &o : order) tr.append_commitment(o.label, sel_comms_[o.sel]);
-        tr.circuit_domain_sep(vk_n_);   // widget.rs:227: the verifier key's own n
+        for (auto &o : order) seed.append_commitment(o.label, sel_comms_[o.sel]);
+        seed.circuit_domain_sep(vk_n_);   // widget.rs:227: the verifier key's own n
+        seed_tr_.reset(new MerlinTranscript(seed.t));
     }
+    PlonkTranscript tr(*seed_tr_);
     for (auto &pi : public_inputs) tr.append_scalar("pi", pi);  // prover.rs:236-238
 
     // composer.rs:1001-1014: the dense public inputs, built on the device from the few (index, value) pairs; a later

@@ -10,6 +10,7 @@
 #include "poly.hpp"
 #include "transcript.hpp"
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -143,6 +144,7 @@ class Prover {
     uint64_t vk_n_ = 0;   // VerifierKey.n: the constraint count for a compiled key (compiler.rs:211-212), the stored value
                           // for one loaded from bytes (widget.rs:102-106); closes the transcript seed (widget.rs:227)
     std::string label_;
+    std::unique_ptr<MerlinTranscript> seed_tr_;   // the transcript after seed_transcript (widget.rs:199-228) for the loaded key
     std::vector<uint64_t> pi_indexes_;
     uint64_t poly_len_[N_SEL] = {0};
     uint32_t widgets_ = 0;

@@ -1,6 +1,8 @@
 """Randomised differential check of the whole prover: circuits built from random sequences of Composer operations
 (arithmetic gates, booleans, selects, range and logic components, curve additions, public inputs), proved on the
-GPU and by the CPU oracle with the same blinders; every commitment, evaluation and challenge must agree.
+GPU and by the CPU oracle with the same blinders; every commitment, evaluation and challenge must agree.  One circuit
+in seven gets a corrupted witness value or public input: both sides must then agree on success or failure as well
+(the GPU decides there between its 4n-coset and 8n-coset quotient).
     python tools/fuzz_prove.py [ITERATIONS] [SEED]"""
 import os
 import sys
@@ -64,9 +66,19 @@ def main():
     tau = M.random_fr_mont(1, seed=seed + 1000)[0]
     srs, _ = orc.srs_powers(orc.g1_generator(), tau, 1024 + 7)
     ctx = zkvm_amd.Context(0)
+    routes = {0: 0, 4: 0, 8: 0}
+    corrupted = 0
     for it in range(iters):
         circ = random_circuit(rng)
         n = circ["n"]
+        if rng.random() < 1 / 7:
+            corrupted += 1
+            if rng.random() < 0.8 or not len(circ["public_inputs"]):
+                circ["wires"] = circ["wires"].copy()
+                circ["wires"][int(rng.integers(0, 4)), int(rng.integers(0, circ["constraints"])), 0] ^= np.uint64(1 << int(rng.integers(0, 60)))
+            else:
+                circ["public_inputs"] = circ["public_inputs"].copy()
+                circ["public_inputs"][int(rng.integers(0, len(circ["public_inputs"]))), 0] ^= np.uint64(4)
         circ["selectors"][11:15] = np.stack([orc.sigma_to_lagrange(circ["sigma_map"][k]) for k in range(4)])
         op = orc.Prover(n, circ["constraints"], circ["selectors"], srs[:n + 7], b"fuzz", circ["pi_indexes"], threads=4)
         bl = circuits.random_blinders(it)
@@ -78,6 +90,9 @@ def main():
             got = gp.prove(circ["wires"].reshape(-1, 4), circ["public_inputs"], bl)
         except zkvm_amd.ZkGpuError as e:
             rc, got = e.code, None
+        except (api.PolynomialDegreeTooLarge, api.PolynomialDegreeIsZero) as e:   # the reference's own error variants
+            rc, got = type(e).__name__, None
+        routes[got["coset"] if got is not None else 0] += 1
         ok = (want["rc"] == 0) == (got is not None)
         if ok and got is not None:
             ok = all(np.array_equal(got[k], want[k]) for k in ("challenges", "evals", "comms_inf", "comms"))
@@ -87,7 +102,8 @@ def main():
         if it % 20 == 0:
             print("iteration", it, "ok (n = %d, %d gates)" % (n, circ["constraints"]), flush=True)
     ctx.close()
-    print("fuzz ok:", iters, "circuits, seed", seed)
+    print("fuzz ok:", iters, "circuits, seed", seed, "- proofs over the 4n coset:", routes[4], "over the 8n coset:", routes[8],
+          "refused by both sides:", routes[0], "- corrupted inputs:", corrupted)
 
 
 if __name__ == "__main__":

@@ -363,6 +363,7 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
         build_key_evals(true, evals4_.as<Fr>(), (size_t)4 * n, stage, true, true);
         read_sigma_tops();
         evals8_built_ = false;
+        evals_.release();   // the 8n vectors of an earlier key; this key's are built when something asks for them
     } else {
         evals_.reserve((size_t)(N_SEL + 2) * ev_len_ * sizeof(Fr));
         build_key_evals(false, evals_.as<Fr>(), ev_len_, stage, true, true);

@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 # per SIMD at the 2.25-2.27 GHz the chip holds under that load, measured with tools/ubench.hip on all 1024 SIMDs at 8
 # waves per SIMD in launches of 8 ms (profiles/r02_ubench.log; nominal 4 cycles at 2.4 GHz would be 614).
 MAD_PEAK_G = 518.0       # G wave-instructions / s, whole chip
-# 32 x 32 -> 64-bit multiply-accumulates of one field product on unsaturated limbs (zkvm_amd/csrc/ff.cuh mul_limbs:
+# 32 x 32 -> 64-bit multiply-accumulates of one field product on unsaturated limbs (zkvm_amd/csrc/ff.hpp mul_limbs:
 # UN^2 partial products + UN (UN + 1) for the Montgomery reduction)
 FQ28_MADS = 14 * 14 + 14 * 15        # 406
 FR_MADS = 9 * 9 + 9 * 10             # 171

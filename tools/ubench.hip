@@ -5,8 +5,8 @@
 #include <cstdio>
 #include <algorithm>
 #include <vector>
-#include "ff.cuh"
-#include "fq28.cuh"
+#include "ff.hpp"
+#include "fq28.hpp"
 
 using namespace zk;
 

@@ -2,7 +2,7 @@
 #include "../../include/zkgpu.h"
 #include "common.hpp"
 #include "msm.hpp"
-#include "fq28.cuh"
+#include "fq28.hpp"
 #include "ntt.hpp"
 #include "poly.hpp"
 #include "prover.hpp"

@@ -16,7 +16,7 @@
 // cases (adding a point to itself, adding a point to its negative) are detected from ZZ3 = 0 and resolved on a
 // slow path, so the sum is the same group element in every case.
 #pragma once
-#include "g1.cuh"
+#include "g1.hpp"
 
 namespace zk {
 

@@ -1,7 +1,7 @@
 // Fr arithmetic on nine unsaturated limbs of 29 bits with lazy reduction: the working form of the transforms' tiles
 // and of the quotient kernel.  One value = uint32_t[9]; "normalised" = limbs 0..7 below 2^29, the rest in limb 8.
 #pragma once
-#include "ff.cuh"
+#include "ff.hpp"
 
 namespace zk {
 

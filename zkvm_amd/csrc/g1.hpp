@@ -3,7 +3,7 @@
 // identity conventions as coset-bls12_381/src/g1.rs:592-736 (identity = (0 : 1 : 0)).  Complete formulas
 // have no exceptional cases, so bucket accumulation needs no branches for P + P or P - P.
 #pragma once
-#include "ff.cuh"
+#include "ff.hpp"
 
 namespace zk {
 

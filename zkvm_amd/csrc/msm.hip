@@ -13,7 +13,7 @@
 //   3. schedule  buckets are ordered by decreasing size so that the lanes of a wave carry equal work; buckets far
 //                above the expected size are cut into fixed-size tasks for whole workgroups;
 //   4. accumulate one thread per bucket adds its entries with the extended-Jacobian mixed addition on 28-bit limbs
-//                (fq28.cuh); oversized buckets are summed by workgroups (strided partial sums + LDS tree);
+//                (fq28.hpp); oversized buckets are summed by workgroups (strided partial sums + LDS tree);
 //   5. reduce    sum_b (b+1) * bucket_b: running sums over segments of L buckets give per-segment totals T_s and
 //                local weighted sums W_s; sum_s s*T_s is then taken bit by bit (Q_k = sum of the T_s whose index
 //                has bit k set), every sum a wide tree;
@@ -23,7 +23,7 @@
 // (multiscalar_mul.rs:150-195) change only the order of group additions; the sum, and so the affine
 // commitment compared by the tests, is the same group element.
 #include "msm.hpp"
-#include "fq28.cuh"
+#include "fq28.hpp"
 #include <cmath>
 #include <cstring>
 #include <vector>

@@ -3,7 +3,7 @@
 // coset-bls12_381/src/coset/multiscalar_mul.rs:143-220).
 #pragma once
 #include "common.hpp"
-#include "g1.cuh"
+#include "g1.hpp"
 #include <vector>
 
 namespace zk {

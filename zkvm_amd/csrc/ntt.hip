@@ -20,7 +20,7 @@
 // twiddles in the same limb form, ready to multiply by; the kernel is bound by integer VALU issue, not by memory.
 #include "ntt.hpp"
 #include <mutex>
-#include "fr9.cuh"
+#include "fr9.hpp"
 
 namespace zk {
 

@@ -2,7 +2,7 @@
 // (plonk/src/fft/domain.rs:106-196): fft / ifft / coset_fft / coset_ifft, natural order in and out.
 #pragma once
 #include "common.hpp"
-#include "ff.cuh"
+#include "ff.hpp"
 #include <map>
 #include <vector>
 

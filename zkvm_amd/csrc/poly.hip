@@ -2,8 +2,8 @@
 // exact field operations gives the reference's limbs; the kernels are free to replace the reference's serial
 // recurrences (per-gate inversion + running product, Horner sums, synthetic division) by scans and reductions.
 #include "poly.hpp"
-#include "fr9.cuh"
-#include "widgets.cuh"
+#include "fr9.hpp"
+#include "widgets.hpp"
 #include <vector>
 
 namespace zk {

@@ -3,7 +3,7 @@
 // division.  All pointers are device pointers; everything is asynchronous on the engine's stream.
 #pragma once
 #include "common.hpp"
-#include "ff.cuh"
+#include "ff.hpp"
 
 namespace zk {
 

@@ -1,7 +1,7 @@
 // Host orchestration of preprocess and prove over the device engines (see prover.hpp).
 #include "prover.hpp"
 #include <map>
-#include "widgets.cuh"
+#include "widgets.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cstring>

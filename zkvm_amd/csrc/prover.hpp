@@ -4,7 +4,7 @@
 // evaluations on the host and every polynomial on the device.
 #pragma once
 #include "common.hpp"
-#include "g1.cuh"
+#include "g1.hpp"
 #include "msm.hpp"
 #include "ntt.hpp"
 #include "poly.hpp"

@@ -5,7 +5,7 @@
 // so they are templated on the product routine M (out-of-line on the device, inline on the host).
 // References: plonk/src/proof_system/widget/{range,logic,ecc/scalar_mul/fixed_base,ecc/curve_addition}/proverkey.rs.
 #pragma once
-#include "ff.cuh"
+#include "ff.hpp"
 
 namespace zk {
 

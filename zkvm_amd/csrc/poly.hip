@@ -615,6 +615,11 @@ __global__ void __launch_bounds__(256) scatter_kernel(Fr *dst, const uint64_t *i
 void PolyEngine::zero_and_scatter(Fr *dst, uint64_t len, const uint64_t *idx_host, const Fr *vals_host, uint32_t count) {
     ZK_HIP(hipMemsetAsync(dst, 0, len * sizeof(Fr), stream_));
     if (!count) return;
+    if (count <= 8) {   // the few values travel with the launch: no copies, no wait
+        bool set[8] = {false, false, false, false, false, false, false, false};
+        patch(dst, idx_host, vals_host, set, (int)count);
+        return;
+    }
     s3_.reserve((size_t)count * (sizeof(Fr) + 8));
     Fr *vals = s3_.as<Fr>();
     uint64_t *idx = reinterpret_cast<uint64_t *>(vals + count);

@@ -902,7 +902,11 @@ uint64_t Prover::quotient_half_coset(const Fr *z, const Fr *const wires[4], cons
     poly_.patch(t_out, idx, lo, sub, 7);            // t_i = r_i - g^4n t_(4n+i)
     for (int i = 0; i < 7; i++) idx[i] = L + i;
     poly_.patch(t_out, idx, hi, set, 7);
-    return poly_.length_without_leading_zeros(t_out, L + 7);    // Polynomial::from_coefficients_vec
+    // Polynomial::from_coefficients_vec drops leading zeros: the top coefficients are known here, so the length
+    // needs the device only if all seven vanish
+    for (int i = 6; i >= 0; i--)
+        if (!hi[i].is_zero()) return L + i + 1;
+    return poly_.length_without_leading_zeros(t_out, L);
 }
 
 // proof_system/proof.rs:511-561
@@ -932,7 +936,8 @@ static Fr first_lagrange_coefficient(const Domain &d, const Fr &tau) {
 // pass over the polynomials on the device.  ch7 = alpha beta gamma range logic fixed var; e in ProofEvaluations order.
 // Returns the number of coefficients written to r_out (the longest term; leading zeros are not dropped here).
 uint64_t Prover::linearization(const Fr ch7[7], const Fr &z_ch, const Fr *e, const Fr *p_z, uint64_t z_len, const Fr *const t_parts[4],
-                               const uint64_t t_lens[4], const std::vector<Fr> &public_inputs, Fr *r_out, uint64_t r_cap) {
+                               const uint64_t t_lens[4], const std::vector<Fr> &public_inputs, Fr *r_out, uint64_t r_cap,
+                               uint64_t z_len_without_leading_zeros) {
     ZK_REQUIRE(loaded(), ZKGPU_ERR_NOT_LOADED, "linearization: no prover key loaded");
     enum { A, B, C, D, AW, BW, DW, QARITH, QC, QL, QR, SG1, SG2, SG3, ZE };
     typedef InlineMul M;
@@ -979,7 +984,8 @@ uint64_t Prover::linearization(const Fr ch7[7], const Fr &z_ch, const Fr *e, con
     cacc = Fr::mul(cacc, Fr::mul(beta, e[ZE]));
     cacc = Fr::mul(cacc, alpha);
     // EvaluationDomain::new(z_poly.degree() - 2) (permutation/proverkey.rs:156)
-    const uint64_t z_eff = poly_.length_without_leading_zeros(p_z, z_len);
+    // (the caller may know it: prove() has written z's top coefficients itself)
+    const uint64_t z_eff = z_len_without_leading_zeros ? z_len_without_leading_zeros : poly_.length_without_leading_zeros(p_z, z_len);
     const uint64_t z_deg = z_eff ? z_eff - 1 : 0;
     const Domain dz = Domain::make(z_deg >= 2 ? z_deg - 2 : 0);
     const Fr l1_z = first_lagrange_coefficient(dz, z_ch);
@@ -1305,7 +1311,11 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     const Fr v_ch = tr.challenge_scalar("v_challenge");
     const Fr *t_parts[4] = {t_low, t_mid, t_high, t_fourth};
     const uint64_t t_lens[4] = {n + 1, n + 1, n + 1, t4_len};
-    const uint64_t r_len = linearization(ch7, z_ch, e, p_z, n + 3, t_parts, t_lens, public_inputs, r_poly, lin_cap);
+    // z's coefficients n, n + 1, n + 2 are its blinders (prover.rs:64-83): its length is known unless all three vanish
+    uint64_t z_eff = 0;
+    for (int i = 2; i >= 0 && !z_eff; i--)
+        if (!bl[8 + i].is_zero()) z_eff = n + i + 1;
+    const uint64_t r_len = linearization(ch7, z_ch, e, p_z, n + 3, t_parts, t_lens, public_inputs, r_poly, lin_cap, z_eff);
     lap(5, t_phase);
     // Both opening witnesses are built first and committed together: the prover's transcript does not absorb
     // w_z_chall_comm (prover.rs:439-479), so v_w does not depend on it.  t[0..3n) is free again and holds the second.

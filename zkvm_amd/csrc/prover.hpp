@@ -90,7 +90,7 @@ class Prover {
     // (kzg10/key.rs:131-146) on device polynomials; see prover.hip
     uint64_t linearization(const Fr ch7[7], const Fr &z_ch, const Fr *evals15, const Fr *p_z, uint64_t z_len,
                            const Fr *const t_parts[4], const uint64_t t_lens[4], const std::vector<Fr> &public_inputs, Fr *r_out,
-                           uint64_t r_cap);
+                           uint64_t r_cap, uint64_t z_len_without_leading_zeros = 0);
     uint64_t aggregate_witness(const Fr *const *polys, const uint64_t *lens, int count, const Fr &point, const Fr &v, Fr *sum_tmp,
                                Fr *out);
     PolyEngine &poly() { return poly_; }

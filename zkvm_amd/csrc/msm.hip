@@ -789,17 +789,87 @@ __device__ __forceinline__ G1Xyzz lds_load_xyzz(const uint32_t *sh, uint32_t slo
     }
     return p;
 }
-// Sums the per-thread accumulators of the first 2 * first_stride threads of a workgroup (the rest must hold the
-// identity or be beyond the data); the total is returned in thread 0.
+// ---- one addition on four lanes ---------------------------------------------------------------------------------
+// The sums at the end of an MSM are trees a few dozen additions deep with ever fewer additions per level: what bounds
+// them is the time of ONE addition on one lane (fourteen field products one after the other), while most lanes idle.
+// The fourteen products of an addition fall into four groups of at most four that do not depend on each other, so four
+// neighbouring lanes (a quad) holding the same two operands take one product each, four times over, and pass the
+// results round with the quad-broadcast data-parallel-primitive move: a third of the dependent arithmetic per addition.
+template <int K>
+__device__ __forceinline__ Fq28 quad_broadcast(const Fq28 &x) {   // lane K of every quad to its four lanes
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.v[i], K * 0x55, 0xf, 0xf, false);
+    return r;
+}
+__device__ __forceinline__ Fq28 quad_pick(uint32_t role, const Fq28 &x0, const Fq28 &x1, const Fq28 &x2, const Fq28 &x3) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const uint32_t lo = (role & 1u) ? x1.v[i] : x0.v[i];
+        const uint32_t hi = (role & 1u) ? x3.v[i] : x2.v[i];
+        r.v[i] = (role & 2u) ? hi : lo;
+    }
+    return r;
+}
+// a + b, both held by all four lanes of a quad (role = lane within the quad); the sum comes back in all four.  Same
+// formulas and operand bounds as xyzz_add; Y3 = R (Q - X3) + (4p - S1) PPP is formed from two reduced products (below
+// 4p, normalised) instead of one double product.
+__device__ G1Xyzz xyzz_add_quad(const G1Xyzz &a, const G1Xyzz &b, uint32_t role) {
+    if (a.is_identity()) return b;
+    if (b.is_identity()) return a;
+    Fq28 prod = Fq28::mul(quad_pick(role, a.x, b.x, a.y, b.y), quad_pick(role, b.zz, a.zz, b.zzz, a.zzz));
+    const Fq28 u1 = quad_broadcast<0>(prod), u2 = quad_broadcast<1>(prod);
+    const Fq28 s1 = quad_broadcast<2>(prod), s2 = quad_broadcast<3>(prod);
+    const Fq28 pd = Fq28::sub4(u2, u1);          // < 6p, limbs < 1.5 * 2^29
+    const Fq28 rd = Fq28::sub4(s2, s1);
+    prod = Fq28::mul(quad_pick(role, pd, rd, a.zz, a.zzz), quad_pick(role, pd, rd, b.zz, b.zzz));
+    const Fq28 pp = quad_broadcast<0>(prod), rr = quad_broadcast<1>(prod);
+    const Fq28 zz12 = quad_broadcast<2>(prod), zzz12 = quad_broadcast<3>(prod);
+    prod = Fq28::mul(quad_pick(role, pd, u1, zz12, rd), quad_pick(role, pp, pp, pp, Fq28::one()));
+    const Fq28 ppp = quad_broadcast<0>(prod), q = quad_broadcast<1>(prod);
+    const Fq28 zz3 = quad_broadcast<2>(prod);
+    if (zz3.is_zero_mod_p()) {                   // the same point, or its negative
+        if (quad_broadcast<3>(prod).is_zero_mod_p()) return xyzz_double(a);
+        return G1Xyzz::identity();
+    }
+    G1Xyzz r;
+    const Fq28 nq = Fq28::sub4(Fq28::zero(), q);
+    r.x = Fq28::normalize(Fq28::add(Fq28::sub4(rr, ppp), Fq28::add(nq, nq)));   // < 14p
+    const Fq28 t = Fq28::sub16(q, r.x);
+    const Fq28 ns1 = Fq28::normalize(Fq28::sub4(Fq28::zero(), s1));            // 4p - s1, limbs < 2^28
+    prod = Fq28::mul(quad_pick(role, rd, ns1, zzz12, zzz12), quad_pick(role, t, ppp, ppp, ppp));
+    r.y = Fq28::normalize(Fq28::add(quad_broadcast<0>(prod), quad_broadcast<1>(prod)));   // < 4p
+    r.zz = zz3;
+    r.zzz = quad_broadcast<2>(prod);
+    return r;
+}
+
+// Sums the per-thread accumulators of the first 2 * first_stride threads of a 256-thread workgroup (the rest must hold
+// the identity or be beyond the data); the total is returned in thread 0.  A level of 128 additions has no lanes to
+// spare and runs one addition per lane; from 64 additions down the accumulators live in LDS and every addition is
+// shared by a quad.
 __device__ __forceinline__ G1Xyzz block_tree_sum(uint32_t *sh, G1Xyzz acc, uint32_t first_stride = 128) {
     const uint32_t tid = threadIdx.x;
-    for (uint32_t stride = first_stride; stride >= 1; stride >>= 1) {
-        if (tid >= stride && tid < 2 * stride) lds_store_xyzz(sh, tid - stride, acc);
+    uint32_t stride = first_stride;
+    if (stride == 128) {
+        if (tid >= 128) lds_store_xyzz(sh, tid - 128, acc);
         __syncthreads();
-        if (tid < stride) acc = xyzz_add(acc, lds_load_xyzz(sh, tid));
+        if (tid < 128) acc = xyzz_add(acc, lds_load_xyzz(sh, tid));
+        __syncthreads();
+        stride = 64;
+    }
+    if (tid < 2 * stride) lds_store_xyzz(sh, tid, acc);
+    __syncthreads();
+    const uint32_t quad = tid >> 2, role = tid & 3u;
+    for (; stride >= 1; stride >>= 1) {
+        G1Xyzz sum;
+        if (quad < stride) sum = xyzz_add_quad(lds_load_xyzz(sh, quad), lds_load_xyzz(sh, quad + stride), role);
+        __syncthreads();
+        if (quad < stride && role == 0) lds_store_xyzz(sh, quad, sum);
         __syncthreads();
     }
-    return acc;
+    return lds_load_xyzz(sh, 0);
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msm_big_partial_kernel(const G1Table28 *points, const uint32_t *sorted,

@@ -673,6 +673,12 @@ __global__ void __launch_bounds__(1024) degree_kernel(const Fr *coeffs, uint64_t
     // blocks walk the vector from the top, so the block holding the leading coefficient is among the first to run
     const uint64_t block_from_top = gridDim.x - 1 - blockIdx.x;
     const uint64_t base = block_from_top * 4096 + threadIdx.x;
+    // a block above has found a coefficient already: nothing down here can raise the result (one thread reads, so
+    // that the whole workgroup takes the same way)
+    __shared__ unsigned long long seen;
+    if (threadIdx.x == 0) seen = *reinterpret_cast<volatile unsigned long long *>(out);
+    __syncthreads();
+    if (seen > block_from_top * 4096 + 4096) return;
     unsigned long long mine = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {

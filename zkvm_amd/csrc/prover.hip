@@ -1109,7 +1109,19 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
 
     // protocol phase 1: wire polynomials (prover.rs:240-269)
     // hipMemcpyDefault: the caller's pointer may be host memory or already resident in HBM
-    ZK_HIP(hipMemcpyAsync(wires, wires_host, 4 * n * sizeof(Fr), hipMemcpyDefault, stream_));
+    // (a witness that already lies in this GPU's memory is read where it is: nothing below writes to it)
+    {
+        hipPointerAttribute_t attr;
+        int current = -1;
+        const bool resident = hipPointerGetAttributes(&attr, wires_host) == hipSuccess && attr.type == hipMemoryTypeDevice &&
+                              hipGetDevice(&current) == hipSuccess && attr.device == current;
+        if (resident) {
+            wires = const_cast<Fr *>(reinterpret_cast<const Fr *>(wires_host));
+        } else {
+            (void)hipGetLastError();   // a pageable host pointer is unknown to the runtime: not an error here
+            ZK_HIP(hipMemcpyAsync(wires, wires_host, 4 * n * sizeof(Fr), hipMemcpyDefault, stream_));
+        }
+    }
     Fr *wp[4] = {p_a, p_b, p_c, p_d};
     for (int k = 0; k < 4; k++) blind_poly(wires + k * n, 1, bl + 2 * k, wp[k]);
     int rc;

@@ -540,42 +540,132 @@ void PolyEngine::linear_combination(const LinArgs &args) {
 }
 
 // ---- synthetic division -------------------------------------------------------------------------------------
-// q_i = sum_{k>i} c_k z^(k-i-1).  With d_k = c_k z^k and T_i = sum_{k>=i} d_k (a reverse additive scan):
-// q_i = T_{i+1} * z^-(i+1).  Powers are produced per thread from one pow and a running product.
-static const uint32_t POW_E = 8;
-template <bool SHIFTED>
-__global__ void __launch_bounds__(256) scale_powers_kernel(const Fr *in, Fr *out, uint64_t n, Fr base) {
-    // SHIFTED = false: out[k] = in[k] * base^k ;  SHIFTED = true: out[k] = in[k+1] * base^(k+1)
-    uint64_t k0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * POW_E;
-    if (k0 >= n) return;
-    Fr p = Fr::pow_u64(base, k0 + (SHIFTED ? 1 : 0));
+// Synthetic division as a suffix Horner scan: h_i = c_i + z h_(i+1) (h_len = 0) and q_i = h_(i+1).  A workgroup takes
+// RUF_B consecutive coefficients: every thread runs Horner over its RUF_E coefficients, the threads' results are
+// combined by a doubling scan whose step d uses the constant z^(RUF_E d), and the workgroup leaves its values as if
+// nothing lay above it, plus its own h at its lowest index.  One workgroup then runs the same scan over those
+// aggregates (step constants z^(RUF_B ...)), and a last pass adds z^(distance to the chunk's top) times the carry that
+// enters each chunk.  Two passes over the data instead of the five of scale / scan / unscale, no inverse of z, and
+// z = 0 needs no special case.
+static const uint32_t RUF_T = 256, RUF_E = 4, RUF_B = RUF_T * RUF_E;
+struct RuffiniConsts {
+    Fr z;
+    Fr low[RUF_E + 1];   // z^k, k <= RUF_E
+    Fr step[8];          // z^(RUF_E 2^k): the doubling scan over the 256 threads of a chunk
+    Fr run;              // z^RUF_B: the serial part of the scan over the chunks
+    Fr top[8];           // z^(RUF_B per_thread 2^k): its doubling part
+    uint32_t per_thread; // chunks each thread of that scan takes
+};
+
+// v_t <- sum_{u >= t} a_u w^(u - t) over the 256 threads of a workgroup, step[k] = w^(2^k); returns the sum of thread
+// t + 1 (what enters thread t from above) and leaves thread 0's sum in *whole
+__device__ __forceinline__ Fr block_suffix_horner(uint32_t *sh /* 2 * 256 * 8 words */, const Fr &mine, const Fr *step, Fr *whole) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t *cur = sh, *nxt = sh + RUF_T * 8;
+    lds_st(cur, tid, mine);
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t d = 1u << k;
+        Fr v = lds_ld(cur, tid);
+        if (tid + d < RUF_T) v = Fr::add(v, Fr::mul(step[k], lds_ld(cur, tid + d)));
+        lds_st(nxt, tid, v);
+        __syncthreads();
+        uint32_t *t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    *whole = lds_ld(cur, 0);
+    Fr above = tid + 1 < RUF_T ? lds_ld(cur, tid + 1) : Fr::zero();
+    __syncthreads();
+    return above;
+}
+
+__global__ void __launch_bounds__(256) ruffini_local_kernel(const Fr *c, uint64_t len, RuffiniConsts k, Fr *out, Fr *aggregates) {
+    __shared__ uint32_t sh[2 * RUF_T * 8];
+    const uint64_t i0 = (uint64_t)blockIdx.x * RUF_B + (uint64_t)threadIdx.x * RUF_E;
+    Fr h[RUF_E];
+    Fr run = Fr::zero();
 #pragma unroll
-    for (uint32_t e = 0; e < POW_E; e++) {
-        uint64_t k = k0 + e;
-        if (k >= n) break;
-        st(out + k, Fr::mul(ld(in + k + (SHIFTED ? 1 : 0)), p));
-        p = Fr::mul(p, base);
+    for (int e = RUF_E - 1; e >= 0; e--) {
+        const uint64_t i = i0 + e;
+        run = Fr::mul(run, k.z);
+        if (i < len) run = Fr::add(run, ld(c + i));
+        h[e] = run;
+    }
+    Fr whole;
+    const Fr above = block_suffix_horner(sh, run, k.step, &whole);
+#pragma unroll
+    for (int e = 0; e < (int)RUF_E; e++) {
+        const uint64_t i = i0 + e;
+        if (i >= 1 && i < len) st(out + (i - 1), Fr::add(h[e], Fr::mul(k.low[RUF_E - e], above)));   // q_(i-1) = h_i
+    }
+    if (threadIdx.x == 0) st(aggregates + blockIdx.x, whole);
+}
+
+// aggregates[b] <- what enters chunk b from above: H_(b+1) with H_b = A_b + z^RUF_B H_(b+1)
+__global__ void __launch_bounds__(256) ruffini_carry_kernel(Fr *aggregates, uint32_t n_chunks, RuffiniConsts k) {
+    __shared__ uint32_t sh[2 * RUF_T * 8];
+    const uint32_t first = threadIdx.x * k.per_thread;
+    Fr run = Fr::zero();
+    for (int e = (int)k.per_thread - 1; e >= 0; e--) {
+        const uint32_t b = first + e;
+        run = Fr::mul(run, k.run);
+        if (b < n_chunks) run = Fr::add(run, ld(aggregates + b));
+    }
+    Fr whole;
+    Fr carry = block_suffix_horner(sh, run, k.top, &whole);   // enters this thread's topmost chunk
+    for (int e = (int)k.per_thread - 1; e >= 0; e--) {
+        const uint32_t b = first + e;
+        if (b >= n_chunks) continue;
+        const Fr mine = ld(aggregates + b);
+        st(aggregates + b, carry);
+        carry = Fr::add(mine, Fr::mul(k.run, carry));
     }
 }
-__global__ void shift_copy_kernel(const Fr *in, Fr *out, uint64_t n) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) st(out + i, ld(in + i + 1));
+
+// powers[e] = z^e, e <= RUF_B
+__global__ void __launch_bounds__(256) ruffini_powers_kernel(Fr z, Fr *powers) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e <= RUF_B) st(powers + e, Fr::pow_u64(z, e));
+}
+
+__global__ void __launch_bounds__(256) ruffini_apply_kernel(Fr *out, uint64_t len, const Fr *carries, const Fr *powers) {
+    const Fr carry = ld(carries + blockIdx.x);
+    if (carry.is_zero()) return;   // the topmost chunk, for one
+    const uint32_t t0 = threadIdx.x * RUF_E;
+    const uint64_t i0 = (uint64_t)blockIdx.x * RUF_B + t0;
+#pragma unroll
+    for (uint32_t e = 0; e < RUF_E; e++) {
+        const uint64_t i = i0 + e;
+        if (i >= 1 && i < len) {
+            Fr *p = out + (i - 1);
+            st(p, Fr::add(ld(p), Fr::mul(ld(powers + (RUF_B - t0 - e)), carry)));   // h_i += z^(chunk top - i) * carry
+        }
+    }
 }
 
 void PolyEngine::ruffini(const Fr *coeffs, uint64_t len, const Fr &root, Fr *out) {
     if (len <= 1) return;  // the quotient is empty
-    const uint64_t m = len - 1;
-    if (root.is_zero()) {  // q_i = c_{i+1}
-        hipLaunchKernelGGL(shift_copy_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, stream_, coeffs, out, m);
-        ZK_HIP(hipGetLastError());
-        return;
+    const uint32_t n_chunks = ceil_div(len, RUF_B);
+    RuffiniConsts k;
+    k.z = root;
+    k.low[0] = Fr::one();
+    for (uint32_t e = 1; e <= RUF_E; e++) k.low[e] = Fr::mul(k.low[e - 1], root);
+    k.step[0] = k.low[RUF_E];
+    for (int j = 1; j < 8; j++) k.step[j] = Fr::sqr(k.step[j - 1]);
+    k.run = Fr::sqr(k.step[7]);   // z^(RUF_E * 256)
+    k.per_thread = ceil_div(n_chunks, RUF_T);
+    k.top[0] = Fr::pow_u64(k.run, k.per_thread);
+    for (int j = 1; j < 8; j++) k.top[j] = Fr::sqr(k.top[j - 1]);
+    s3_.reserve(((size_t)n_chunks + RUF_B + 1) * sizeof(Fr));
+    Fr *aggregates = s3_.as<Fr>(), *powers = aggregates + n_chunks;
+    hipLaunchKernelGGL(ruffini_local_kernel, dim3(n_chunks), dim3(RUF_T), 0, stream_, coeffs, len, k, out, aggregates);
+    if (n_chunks > 1) {
+        hipLaunchKernelGGL(ruffini_powers_kernel, dim3(ceil_div(RUF_B + 1, 256)), dim3(256), 0, stream_, root, powers);
+        hipLaunchKernelGGL(ruffini_carry_kernel, dim3(1), dim3(RUF_T), 0, stream_, aggregates, n_chunks, k);
+        hipLaunchKernelGGL(ruffini_apply_kernel, dim3(n_chunks), dim3(RUF_T), 0, stream_, out, len, aggregates, powers);
     }
-    s3_.reserve((size_t)len * sizeof(Fr));
-    Fr *tmp = s3_.as<Fr>();
-    const Fr root_inv = Fr::inv(root);
-    hipLaunchKernelGGL((scale_powers_kernel<false>), dim3(ceil_div(ceil_div(len, POW_E), 256)), dim3(256), 0, stream_, coeffs, tmp, len, root);
-    inclusive_scan<OpAdd, true>(stream_, tmp, tmp, len, s2_);
-    hipLaunchKernelGGL((scale_powers_kernel<true>), dim3(ceil_div(ceil_div(m, POW_E), 256)), dim3(256), 0, stream_, tmp, out, m, root_inv);
     ZK_HIP(hipGetLastError());
 }
 

@@ -23,6 +23,18 @@ __device__ __forceinline__ void ntt_bias(uint32_t *b) {   // M r with M = 4 * 2^
 #pragma unroll
     for (int i = 0; i < 9; i++) b[i] = T[KM][i];
 }
+// The same multiples of r with the limbs below the top raised by 2^30: for a subtrahend that is the limb-wise sum of
+// two normalised values and has not been through a carry sweep (limbs up to 2^30 - 2)
+template <int KM>
+__device__ __forceinline__ void ntt_bias_wide(uint32_t *b) {
+    constexpr uint32_t T[4][9] = {
+        {0x40000004u, 0x5fffffdeu, 0x5e5bfefdu, 0x4d2017fdu, 0x560154edu, 0x50101341u, 0x5483339bu, 0x4994cebcu, 0x01cfb69bu},
+        {0x40000008u, 0x5fffffbeu, 0x5cb7fdfdu, 0x5a402ffdu, 0x4c02a9dcu, 0x40202685u, 0x49066739u, 0x53299d7bu, 0x039f6d38u},
+        {0x40000010u, 0x5fffff7eu, 0x596ffbfdu, 0x54805ffdu, 0x580553bbu, 0x40404d0cu, 0x520cce74u, 0x46533af8u, 0x073eda73u},
+        {0x40000020u, 0x5ffffefeu, 0x52dff7fdu, 0x4900bffdu, 0x500aa779u, 0x40809a1bu, 0x44199ceau, 0x4ca675f3u, 0x0e7db4e8u}};
+#pragma unroll
+    for (int i = 0; i < 9; i++) b[i] = T[KM][i];
+}
 __device__ __forceinline__ void u9_load(const uint32_t *lds, uint32_t E, uint32_t e, uint32_t *x) {
 #pragma unroll
     for (int k = 0; k < 9; k++) x[k] = lds[k * E + e];

@@ -142,8 +142,17 @@ __device__ __forceinline__ void ntt_load_bias(uint32_t km, uint32_t *bias) {
     else if (km == 2) ntt_bias<2>(bias);
     else ntt_bias<3>(bias);
 }
-// One decimation-in-frequency butterfly on tile limbs: x <- x + y (normalised), y <- (x - y + M r) * w with the
-// stage's bias M r; tw == nullptr stands for w = 1 (the last stage of a plain table).
+__device__ __forceinline__ void ntt_load_bias_wide(uint32_t km, uint32_t *bias) {
+    if (km == 0) ntt_bias_wide<0>(bias);
+    else if (km == 1) ntt_bias_wide<1>(bias);
+    else if (km == 2) ntt_bias_wide<2>(bias);
+    else ntt_bias_wide<3>(bias);
+}
+// One decimation-in-frequency butterfly on tile limbs: x <- x + y (normalised when NORM_SUM), y <- (x - y + M r) * w
+// with the stage's bias M r; tw == nullptr stands for w = 1 (the last stage of a plain table).  Without the carry sweep
+// the sum's limbs reach 2^30 - 2: the next stage then subtracts it under the wide bias (the product's column sums
+// still fit: 9 * 2.5 * 2^30 * 2^29 + 9 * 2^58 < 2^64) and sweeps its own sum.
+template <bool NORM_SUM = true>
 __device__ __forceinline__ void u9_butterfly(uint32_t *x, uint32_t *y, const uint32_t *bias, const Tw9 *tw) {
     uint32_t d[9];
 #pragma unroll
@@ -151,7 +160,7 @@ __device__ __forceinline__ void u9_butterfly(uint32_t *x, uint32_t *y, const uin
         d[k] = x[k] + (bias[k] - y[k]);
         x[k] += y[k];
     }
-    u9_normalize(x);
+    if (NORM_SUM) u9_normalize(x);
     if (tw) {
         uint32_t w[9];
         tw_load(tw, w);
@@ -289,9 +298,13 @@ __global__ void __launch_bounds__(MAX_THREADS) ntt_pass_kernel(NttPassArgs a) {
         const uint32_t km_a = stage & 3u, km_b = (stage + 1) & 3u;
         const bool reduce_a = km_a == 0 && stage > 0, reduce_b = km_b == 0;
         const bool has_w_b = h_b > 1 || !a.unit_last;
+        // the first of the two stages leaves its sums without a carry sweep unless the second one starts with a
+        // reduction (which wants normalised limbs)
+        const bool lazy = !reduce_b;
         uint32_t bias_a[9], bias_b[9];
         ntt_load_bias(km_a, bias_a);
-        ntt_load_bias(km_b, bias_b);
+        if (lazy) ntt_load_bias_wide(km_b, bias_b);
+        else ntt_load_bias(km_b, bias_b);
         for (uint32_t g = tid; g < (E >> 2); g += nt) {
             const uint32_t t = g & (T - 1);
             const uint32_t jg = g >> a.log_t;
@@ -311,8 +324,13 @@ __global__ void __launch_bounds__(MAX_THREADS) ntt_pass_kernel(NttPassArgs a) {
             }
             const uint32_t col = (a.last ? 0u : t) + col_term;
             const Tw9 *tw_a = a.tw + (h_a - 1) + (off << a.b0) + col;         // row offsets off and off + hq
-            u9_butterfly(x0, x2, bias_a, tw_a);
-            u9_butterfly(x1, x3, bias_a, tw_a + ((size_t)hq << a.b0));
+            if (lazy) {
+                u9_butterfly<false>(x0, x2, bias_a, tw_a);
+                u9_butterfly<false>(x1, x3, bias_a, tw_a + ((size_t)hq << a.b0));
+            } else {
+                u9_butterfly(x0, x2, bias_a, tw_a);
+                u9_butterfly(x1, x3, bias_a, tw_a + ((size_t)hq << a.b0));
+            }
             if (reduce_b) {
                 u9_qreduce(x0);
                 u9_qreduce(x1);

@@ -197,6 +197,22 @@ int zkgpu_g1_bucket_selfcheck_tree(const uint64_t *xy, const uint8_t *infinity, 
 /* G1Affine::to_bytes (coset-bls12_381/src/g1/coset.rs:54-71): the 48-byte compressed encoding that the
  * transcript absorbs.  Host-only. */
 int zkgpu_g1_compress(const uint64_t xy[12], uint8_t infinity, uint8_t out[48]);
+/* G1Affine::from_bytes (coset-bls12_381/src/g1/coset.rs:73-140): compressed x with its three flag bits, y from the
+ * curve equation and the sort flag, subgroup check.  ZKGPU_ERR_INVALID_ARG where the reference returns Err.  Host-only. */
+int zkgpu_g1_decompress(const uint8_t in[48], uint64_t out_xy[12], uint8_t *out_infinity);
+
+/* Proof::to_bytes / Proof::from_bytes (plonk/src/proof_system/proof.rs:95-157): the 1008-byte proof the reference's
+ * service writes to its proof files (merkle-plonk/src/lib.rs:335-352) — the eleven commitments a b c d z t_low t_mid
+ * t_high t_fourth w_z w_zw in the compressed 48-byte form, then the fifteen evaluations in ProofEvaluations order
+ * (proof_system/linearization_poly.rs:29-74,76-137) as canonical little-endian scalars.  The arrays are those of
+ * zkgpu_prove (commitments x | y of 12 limbs with their infinity flags, evaluations in Montgomery form).  from_bytes
+ * returns ZKGPU_ERR_INVALID_ARG where the reference returns an Err: a point encoding that is not a compressed
+ * subgroup point, a scalar not below the modulus.  Host-only. */
+#define ZKGPU_PROOF_BYTES 1008
+int zkgpu_proof_to_bytes(const uint64_t *comms_xy, const uint8_t *comms_infinity, const uint64_t *evals,
+                         uint8_t out[ZKGPU_PROOF_BYTES]);
+int zkgpu_proof_from_bytes(const uint8_t in[ZKGPU_PROOF_BYTES], uint64_t *comms_xy, uint8_t *comms_infinity,
+                           uint64_t *evals);
 
 /* ---- ProverKey / Prover ---------------------------------------------------------------------------------- */
 /* Order of the 15 selector / sigma vectors in every array below:

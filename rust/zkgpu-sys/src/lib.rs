@@ -111,6 +111,9 @@ extern "C" {
     pub fn zkgpu_prover_key_poly(ctx: *mut zkgpu_ctx, which: c_int, out: *mut u64) -> c_int;
     pub fn zkgpu_prover_key_eval8n(ctx: *mut zkgpu_ctx, which: c_int, out: *mut u64) -> c_int;
     pub fn zkgpu_prover_key_eval_len(ctx: *const zkgpu_ctx) -> usize;
+    pub fn zkgpu_g1_decompress(input: *const u8, out_xy: *mut u64, out_infinity: *mut u8) -> c_int;
+    pub fn zkgpu_proof_to_bytes(comms_xy: *const u64, comms_infinity: *const u8, evals: *const u64, out: *mut u8) -> c_int;
+    pub fn zkgpu_proof_from_bytes(input: *const u8, comms_xy: *mut u64, comms_infinity: *mut u8, evals: *mut u64) -> c_int;
     pub fn zkgpu_prover_force_full_coset(ctx: *mut zkgpu_ctx, on: c_int) -> c_int;
     pub fn zkgpu_prover_last_proof_coset(ctx: *const zkgpu_ctx) -> c_int;
     pub fn zkgpu_quotient(ctx: *mut zkgpu_ctx, polys: *const u64, lens: *const usize, challenges7: *const u64,

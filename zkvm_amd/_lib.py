@@ -85,6 +85,9 @@ SIGNATURES = {
     "zkgpu_prover_key_poly": (C.c_int, [_P, C.c_int, _P]),
     "zkgpu_prover_key_eval_len": (C.c_size_t, [_P]),
     "zkgpu_prover_key_eval8n": (C.c_int, [_P, C.c_int, _P]),
+    "zkgpu_g1_decompress": (C.c_int, [_P, _P, _P]),
+    "zkgpu_proof_to_bytes": (C.c_int, [_P, _P, _P, _P]),
+    "zkgpu_proof_from_bytes": (C.c_int, [_P, _P, _P, _P]),
     "zkgpu_prover_force_full_coset": (C.c_int, [_P, C.c_int]),
     "zkgpu_prover_last_proof_coset": (C.c_int, [_P]),
     "zkgpu_quotient": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_size_t)]),

@@ -301,6 +301,50 @@ def g1_compress(xy, infinity=0):
     return bytes(out)
 
 
+def g1_decompress(data):
+    """G1Affine::from_bytes (coset-bls12_381/src/g1/coset.rs:73-140) -> (xy limbs (12,), infinity flag); ValueError
+    where the reference returns Err."""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    if buf.shape[0] != 48:
+        raise ValueError("a compressed G1 point has 48 bytes")
+    xy = np.zeros(12, dtype=np.uint64)
+    inf = np.zeros(1, dtype=np.uint8)
+    rc = _lib.lib().zkgpu_g1_decompress(buf.ctypes.data, xy.ctypes.data, inf.ctypes.data)
+    if rc != 0:
+        raise ValueError("not a compressed point of the G1 subgroup")
+    return xy, int(inf[0])
+
+
+PROOF_BYTES = 1008
+
+
+def proof_to_bytes(proof):
+    """Proof::to_bytes (plonk/src/proof_system/proof.rs:95-123) of what Prover.prove returns -> 1008 bytes."""
+    comms = _np_u64(proof["comms"], 12)
+    inf = np.ascontiguousarray(proof["comms_inf"], dtype=np.uint8)
+    evals = _np_u64(proof["evals"], 4)
+    assert comms.shape[0] == 11 and inf.shape[0] == 11 and evals.shape[0] == 15
+    out = np.zeros(PROOF_BYTES, dtype=np.uint8)
+    rc = _lib.lib().zkgpu_proof_to_bytes(comms.ctypes.data, inf.ctypes.data, evals.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise ZkGpuError(rc, "proof_to_bytes")
+    return bytes(out)
+
+
+def proof_from_bytes(data):
+    """Proof::from_bytes (proof.rs:125-157) -> dict(comms, comms_inf, evals); ValueError where the reference returns Err."""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    if buf.shape[0] != PROOF_BYTES:
+        raise ValueError("a proof has %d bytes" % PROOF_BYTES)
+    comms = np.zeros((11, 12), dtype=np.uint64)
+    inf = np.zeros(11, dtype=np.uint8)
+    evals = np.zeros((15, 4), dtype=np.uint64)
+    rc = _lib.lib().zkgpu_proof_from_bytes(buf.ctypes.data, comms.ctypes.data, inf.ctypes.data, evals.ctypes.data)
+    if rc != 0:
+        raise ValueError("malformed proof bytes")
+    return dict(comms=comms, comms_inf=inf, evals=evals)
+
+
 class EvaluationDomain:
     """EvaluationDomain::new(num_coeffs) and its four transforms (plonk/src/fft/domain.rs:106-196)."""
 

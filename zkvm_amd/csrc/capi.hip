@@ -659,6 +659,59 @@ int zkgpu_prover_key_eval8n(zkgpu_ctx *ctx, int which, uint64_t *out) {
     });
 }
 
+int zkgpu_g1_decompress(const uint8_t in[48], uint64_t out_xy[12], uint8_t *out_infinity) {
+    if (!in || !out_xy || !out_infinity) return ZKGPU_ERR_INVALID_ARG;
+    std::string err;
+    bool ok = false;
+    const int rc = no_throw(err, [&] {
+        AffineOut p;
+        ok = g1_decompress(in, p);
+        if (ok) {
+            memcpy(out_xy, p.x.v, 48);
+            memcpy(out_xy + 6, p.y.v, 48);
+            *out_infinity = p.infinity ? 1 : 0;
+        }
+    });
+    if (rc != ZKGPU_OK) return rc;
+    return ok ? ZKGPU_OK : ZKGPU_ERR_INVALID_ARG;
+}
+
+// Proof::to_bytes (plonk/src/proof_system/proof.rs:95-123): eleven compressed commitments, then the fifteen
+// evaluations as canonical little-endian scalars (ProofEvaluations::to_bytes, linearization_poly.rs:76-101)
+int zkgpu_proof_to_bytes(const uint64_t *comms_xy, const uint8_t *comms_infinity, const uint64_t *evals, uint8_t out[ZKGPU_PROOF_BYTES]) {
+    if (!comms_xy || !comms_infinity || !evals || !out) return ZKGPU_ERR_INVALID_ARG;
+    for (int k = 0; k < 11; k++) {
+        const int rc = zkgpu_g1_compress(comms_xy + 12 * k, comms_infinity[k], out + 48 * k);
+        if (rc != ZKGPU_OK) return rc;
+    }
+    for (int k = 0; k < 15; k++) {
+        Fr e;
+        memcpy(e.v, evals + 4 * k, 32);
+        if (!e.below_modulus()) return ZKGPU_ERR_INVALID_ARG;
+        const Fr c = Fr::from_mont(e);
+        memcpy(out + 11 * 48 + 32 * k, c.v, 32);
+    }
+    return ZKGPU_OK;
+}
+
+// Proof::from_bytes (proof.rs:125-157, linearization_poly.rs:103-137): ZKGPU_ERR_INVALID_ARG where the reference
+// returns an Err (an invalid point encoding, a point outside the subgroup, a scalar not below the modulus)
+int zkgpu_proof_from_bytes(const uint8_t in[ZKGPU_PROOF_BYTES], uint64_t *comms_xy, uint8_t *comms_infinity, uint64_t *evals) {
+    if (!in || !comms_xy || !comms_infinity || !evals) return ZKGPU_ERR_INVALID_ARG;
+    for (int k = 0; k < 11; k++) {
+        const int rc = zkgpu_g1_decompress(in + 48 * k, comms_xy + 12 * k, comms_infinity + k);
+        if (rc != ZKGPU_OK) return rc;
+    }
+    for (int k = 0; k < 15; k++) {
+        Fr c;
+        memcpy(c.v, in + 11 * 48 + 32 * k, 32);
+        if (!c.below_modulus()) return ZKGPU_ERR_INVALID_ARG;   // BlsScalar::from_bytes (scalar.rs:256-265)
+        const Fr e = Fr::to_mont(c);
+        memcpy(evals + 4 * k, e.v, 32);
+    }
+    return ZKGPU_OK;
+}
+
 int zkgpu_prover_force_full_coset(zkgpu_ctx *ctx, int on) {
     return guarded(ctx, [&] { ctx->prover->force_full_coset(on != 0); });
 }

@@ -425,7 +425,7 @@ static bool fq_lex_largest(const Fq &y_mont) {
 }
 // G1Affine::from_bytes (coset-bls12_381/src/g1/coset.rs:73-140): compressed x with the three flag bits, y from the
 // curve equation, sign from the sort flag, then the subgroup check.  Returns false where the reference returns Err.
-static bool g1_decompress(const uint8_t in[48], AffineOut &out) {
+bool g1_decompress(const uint8_t in[48], AffineOut &out) {
     const bool compressed = (in[0] >> 7) & 1, infinity = (in[0] >> 6) & 1, sort = (in[0] >> 5) & 1;
     if (!compressed) return false;
     Fq xc;

@@ -21,6 +21,9 @@ struct AffineOut {
     bool infinity;
 };
 
+// G1Affine::from_bytes (coset-bls12_381/src/g1/coset.rs:73-140) on the host: false where the reference returns Err
+bool g1_decompress(const uint8_t in[48], AffineOut &out);
+
 struct ProofOut {
     AffineOut comms[11];  // a b c d z t_low t_mid t_high t_fourth w_z w_zw   (proof_system/proof.rs:29-65)
     Fr evals[15];         // ProofEvaluations field order (linearization_poly.rs:29-74)

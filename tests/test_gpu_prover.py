@@ -198,6 +198,8 @@ def test_prove(ctx, orc, srs, log_n, seed):
     for k in range(11):
         assert np.array_equal(got["comms"][k], want["comms"][k]), api.COMMITMENT_NAMES[k]
     assert got["timings_ms"]["total"] > 0
+    # and as the 1008 bytes the reference writes to a proof file (proof_system/proof.rs:95-123)
+    assert api.proof_to_bytes(got) == api.proof_to_bytes(want)
 
 
 def test_prove_twice_same_key(ctx, orc, srs):

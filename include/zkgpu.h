@@ -371,6 +371,13 @@ int zkgpu_merkle_batch_circuit(uint32_t height, uint32_t k, const uint64_t *leav
                                const uint8_t *positions, const uint64_t *roots, const uint64_t *arc, const uint64_t *mds,
                                const uint64_t tag[4], uint64_t n, uint64_t *selectors, uint64_t *sigma_map, uint64_t *wires,
                                uint64_t *pi_indexes, uint64_t *public_inputs, uint32_t threads);
+/* The witness-dependent tables of the same circuit alone: wires 4 x n and the k public-input values.  This is what the
+ * reference's Prover::prove recomputes per proof by running the circuit on a fresh Composer
+ * (plonk/src/composer/prover.rs:214-238) while the selector and permutation tables stay with the key; same inputs and
+ * same values as zkgpu_merkle_batch_circuit writes to those two outputs. */
+int zkgpu_merkle_batch_witness(uint32_t height, uint32_t k, const uint64_t *leaves, const uint64_t *branches,
+                               const uint8_t *positions, const uint64_t *roots, const uint64_t *arc, const uint64_t *mds,
+                               const uint64_t tag[4], uint64_t n, uint64_t *wires, uint64_t *public_inputs, uint32_t threads);
 /* Hash::digest(Domain::Merkle4, four values) (coset-poseidon/src/hash.rs:144-148 over hades/permutation/scalar.rs:33-67)
  * for `count` groups of four inputs: the node hash of the Poseidon-Merkle tree (poseidon-merkle/src/lib.rs:133-160). */
 int zkgpu_poseidon_merkle4(const uint64_t *inputs, size_t count, const uint64_t *arc, const uint64_t *mds, const uint64_t tag[4],

@@ -137,6 +137,9 @@ extern "C" {
                                       roots: *const u64, arc: *const u64, mds: *const u64, tag: *const u64, n: u64,
                                       selectors: *mut u64, sigma_map: *mut u64, wires: *mut u64, pi_indexes: *mut u64,
                                       public_inputs: *mut u64, threads: u32) -> c_int;
+    pub fn zkgpu_merkle_batch_witness(height: u32, k: u32, leaves: *const u64, branches: *const u64, positions: *const u8,
+                                      roots: *const u64, arc: *const u64, mds: *const u64, tag: *const u64, n: u64,
+                                      wires: *mut u64, public_inputs: *mut u64, threads: u32) -> c_int;
     pub fn zkgpu_poseidon_merkle4(inputs: *const u64, count: usize, arc: *const u64, mds: *const u64, tag: *const u64,
                                   out: *mut u64) -> c_int;
     pub fn zkgpu_transcript_challenge(label: *const c_char, msg_label: *const c_char, msg: *const u8, msg_len: usize,

@@ -292,6 +292,11 @@ def test_native_circuit_of_one_opening_equals_the_composer(height):
     assert got["n"] == want["n"] and got["constraints"] == want["constraints"] and got["pi_indexes"] == want["pi_indexes"]
     for key in ("selectors", "sigma_map", "wires", "public_inputs"):
         assert np.array_equal(got[key], want[key]), key
+    # the per-proof half alone (what Prover::prove regenerates, prover.rs:214-238), into arrays used before
+    wires, pi = P.batch_opening_witness([tree.opening(spots[0])], [tree.leaves[spots[0]]], threads=1)
+    assert not np.array_equal(wires, want["wires"])
+    again = P.batch_opening_witness([opening], [leaf], threads=1, out=(wires, pi))
+    assert again[0] is wires and np.array_equal(wires, want["wires"]) and np.array_equal(pi, want["public_inputs"])
 
 
 def test_native_batch_circuit_equals_the_composer_on_several_openings(orc):
@@ -314,6 +319,8 @@ def test_native_batch_circuit_equals_the_composer_on_several_openings(orc):
         assert got["n"] == want["n"] and got["constraints"] == want["constraints"] and got["pi_indexes"] == want["pi_indexes"]
         for key in ("selectors", "sigma_map", "wires", "public_inputs"):
             assert np.array_equal(got[key], want[key]), (key, threads)
+        wires, pi = P.batch_opening_witness(openings, leaves, threads=threads)
+        assert np.array_equal(wires, want["wires"]) and np.array_equal(pi, want["public_inputs"]), threads
     assert [M.fr_from_mont(v) for v in got["public_inputs"]] == [tree.root()] * 5
     op, srs, tau = _prover(orc, got, b"merkle-batch")
     proof = op.prove(got["wires"], got["public_inputs"], circuits.random_blinders(5))

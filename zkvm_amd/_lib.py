@@ -101,6 +101,7 @@ SIGNATURES = {
     "zkgpu_merkle_batch_circuit_size": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "zkgpu_merkle_batch_circuit": (C.c_int, [C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, _P, C.c_uint64, _P, _P, _P, _P, _P,
                                              C.c_uint32]),
+    "zkgpu_merkle_batch_witness": (C.c_int, [C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, _P, C.c_uint64, _P, _P, C.c_uint32]),
     "zkgpu_poseidon_merkle4": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P]),
     "zkgpu_transcript_challenge": (C.c_int, [C.c_char_p, C.c_char_p, _P, C.c_size_t, C.c_char_p, _P, C.c_size_t]),
 }

@@ -383,6 +383,40 @@ def merkle4_native(groups):
     return [v * circuits.MONT_INV % R for v in circuits.limbs_to_ints(out)]
 
 
+def batch_opening_witness(openings, leaf_hashes, threads=8, out=None):
+    """The per-proof half of batch_opening_circuit: the wire columns (4 x n) and the k public roots of the same circuit
+    for other leaves, as the reference's Prover::prove regenerates them for every proof
+    (plonk/src/composer/prover.rs:214-238).  `out` = (wires, public_inputs) arrays to fill again.  Returns them."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    k = len(openings)
+    assert k >= 1 and len(leaf_hashes) == k
+    height = len(openings[0].branch)
+    assert all(len(o.branch) == height and len(o.positions) == height for o in openings)
+    lib = _lib.lib()
+    gates, n = C.c_uint64(0), C.c_uint64(0)
+    rc = lib.zkgpu_merkle_batch_circuit_size(height, k, C.byref(gates), C.byref(n))
+    if rc != 0:
+        raise _lib.ZkGpuError(rc, "merkle_batch_circuit_size")
+    n = int(n.value)
+    leaves = np.ascontiguousarray(_mont_table(leaf_hashes))
+    branches = np.ascontiguousarray(_mont_table([v for o in openings for level in o.branch for v in level]))
+    positions = np.ascontiguousarray([p for o in openings for p in o.positions], dtype=np.uint8)
+    roots = np.ascontiguousarray(_mont_table([o.root for o in openings]))
+    arc, mds, tag = _native_constants()
+    if out is None:
+        out = (np.empty((4, n, 4), dtype=np.uint64), np.empty((k, 4), dtype=np.uint64))
+    wires, pi_val = out
+    assert wires.shape == (4, n, 4) and pi_val.shape == (k, 4) and wires.flags.c_contiguous and pi_val.flags.c_contiguous
+    rc = lib.zkgpu_merkle_batch_witness(height, k, leaves.ctypes.data, branches.ctypes.data, positions.ctypes.data,
+                                        roots.ctypes.data, arc.ctypes.data, mds.ctypes.data, tag.ctypes.data, n,
+                                        wires.ctypes.data, pi_val.ctypes.data, int(threads))
+    if rc != 0:
+        raise _lib.ZkGpuError(rc, "merkle_batch_witness")
+    return wires, pi_val
+
+
 def batch_opening_circuit(openings, leaf_hashes, threads=8):
     """One circuit proving k Merkle openings (trees of one height), each tied to its public root: the reference's
     OpeningCircuit (merkle-plonk/src/lib.rs:117-131) repeated k times on one Composer, generated natively.  Returns

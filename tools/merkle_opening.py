@@ -1,11 +1,14 @@
 """The reference's own workload on the GPU prover: a Poseidon-Merkle tree, one circuit compiled once, then one proof
 per opened leaf, each checked by the verifier (merkle-plonk/src/lib.rs:275-332 proves one opening per proof in a
 loop; circuit: merkle-plonk/src/lib.rs:117-131).
-    python tools/merkle_opening.py HEIGHT [OPENINGS]
-A tree of height H has 4^H leaves; its opening circuit has about 1 010 gates per level."""
+    python tools/merkle_opening.py HEIGHT [OPENINGS] [CONTEXTS]
+A tree of height H has 4^H leaves; its opening circuit has about 1 010 gates per level.  With CONTEXTS > 1 a second
+leg runs the same loop on that many host threads, each with a context and a prover of its own on the one GPU and each
+generating its witnesses itself: the openings per second of a service that proves one request after another."""
 import os
 import random
 import sys
+import threading
 import time
 
 import numpy as np
@@ -24,6 +27,7 @@ def main():
     from zkvm_amd import api, circuits, poseidon as P
     height = int(sys.argv[1])
     openings = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    contexts = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     label = b"merkle-opening"
 
     tree = P.Tree(height)
@@ -85,7 +89,59 @@ def main():
         print("leaf %d: witness %.1f ms on the host, proof %.2f ms, accepted" % (p, 1e3 * host_s, times[-1]), flush=True)
     print("height %d: %d openings proved and verified, %.2f ms per proof (median)" % (height, len(times), float(np.median(times))),
           flush=True)
+    if contexts > 1:
+        service(contexts, height, tree, positions, circ, label, tau, gxy, root, (sxy, sinf, h, tau_h))
     ctx.close()
+
+
+def service(contexts, height, tree, positions, circ, label, tau, gxy, root, verifier_side, rounds=24):
+    """`contexts` host threads, each: witness of the next leaf (one core), copy to the GPU, prove.  Every thread's last
+    proof goes through the verifier."""
+    import torch
+    import model as M
+    import plonk_check
+    import zkvm_amd
+    from oracle import pyoracle as orc
+    from zkvm_amd import api, circuits, poseidon as P
+    n = circ["n"]
+    sxy, sinf, h, tau_h = verifier_side
+    workers = []
+    for _ in range(contexts):
+        ctx = zkvm_amd.Context(0)
+        ctx.srs_setup(tau, gxy, n + 7)
+        gp = api.Prover(ctx, n, circ["constraints"], circ["selectors"].reshape(-1, 4), label, circ["pi_indexes"])
+        ctx.sync()
+        workers.append((ctx, gp))
+    openings = [(tree.opening(p), tree.leaves[p]) for p in positions]
+    last = [None] * contexts
+
+    def run(k, count):
+        _, gp = workers[k]
+        buffers = None
+        for i in range(count):
+            opening, leaf = openings[(k + i * contexts) % len(openings)]
+            buffers = P.batch_opening_witness([opening], [leaf], threads=1, out=buffers)
+            wires = torch.from_numpy(buffers[0].reshape(-1, 4).view(np.int64)).cuda()
+            proof = gp.prove(wires, buffers[1], circuits.random_blinders(k * 1000 + i))
+        last[k] = (proof, buffers[1].copy())
+
+    for k in range(contexts):
+        run(k, 2)                       # warm-up, serially
+    threads = [threading.Thread(target=run, args=(k, rounds)) for k in range(contexts)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    elapsed = time.perf_counter() - t0
+    for k, (proof, pi) in enumerate(last):
+        assert M.fr_from_mont(pi[0]) == root
+        assert plonk_check.verify(n, circ["constraints"], label, proof, sxy, sinf, pi, circ["pi_indexes"], gxy, h, tau_h, orc), k
+    total = contexts * rounds
+    print("height %d, %d contexts on one GPU, witnesses generated in the loop: %d openings in %.3f s -> %.0f openings/s; "
+          "the last proof of every thread accepted" % (height, contexts, total, elapsed, total / elapsed), flush=True)
+    for ctx, _ in workers:
+        ctx.close()
 
 
 if __name__ == "__main__":

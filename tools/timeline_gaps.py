@@ -25,11 +25,13 @@ busy = 0
 per = defaultdict(lambda: [0, 0])
 gaps = []
 prev_end = step[0][0]
-for s, e, name in step:
-    short = name.split("(")[0].split("<")[0].replace("zk::", "")
+prev_short = "-"
+for pos, (s, e, name) in enumerate(step):
+    short = name.split("(")[0].split("<")[0].replace("zk::", "").replace("void ", "")
     gap = s - prev_end
     if gap > 0:
-        gaps.append((gap, short))
+        gaps.append((gap, "%s  (launch %d, %.2f ms into the step, after %s)" % (short, pos, (s - step[0][0]) / 1e6, prev_short)))
+    prev_short = short
     busy += e - max(s, prev_end) if e > prev_end else 0
     prev_end = max(prev_end, e)
     per[short][0] += e - s

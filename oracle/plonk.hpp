@@ -12,6 +12,9 @@
 #include "msm.hpp"
 #include "transcript.hpp"
 #include <array>
+#include <atomic>
+#include <thread>
+#include <vector>
 #include <string>
 
 namespace oracle {
@@ -182,17 +185,35 @@ static inline Fr perm_quotient_i(const ProverKey &pk, size_t i, const Fr &a, con
 // ---- preprocess: compiler.rs:89-147 (selector iFFTs), 239-306 (8n coset evaluations), 353-354 ----
 // `selector_evals[k]` holds the n gate-wise values of selector k (S1..S4 = sigma values, i.e. the
 // output of build_permutation_lagrange_mapping, permutation.rs:111-141).
-static inline ProverKey preprocess(size_t n, const FrVec selector_evals[N_SEL]) {
+// The selectors are independent of each other: with n_threads > 1 they are transformed side by side (the values do
+// not depend on it; the reference runs them one after the other).
+static inline ProverKey preprocess(size_t n, const FrVec selector_evals[N_SEL], unsigned n_threads = 1) {
     ProverKey pk;
     EvaluationDomain domain(n - 1 ? n - 1 : 1);
     pk.n = domain.size;
     EvaluationDomain domain_8n(8 * domain.size);
-    for (int k = 0; k < N_SEL; k++) {
-        pk.poly[k] = Poly::from_coefficients_vec(domain.ifft(selector_evals[k]));
-        pk.eval8n[k] = domain_8n.coset_fft(pk.poly[k].c);
+    auto one = [&](int k) {
+        if (k < N_SEL) {
+            pk.poly[k] = Poly::from_coefficients_vec(domain.ifft(selector_evals[k]));
+            pk.eval8n[k] = domain_8n.coset_fft(pk.poly[k].c);
+        } else if (k == N_SEL) {
+            pk.linear_evaluations = domain_8n.coset_fft(FrVec{fr_zero(), fr_one()});
+        } else {
+            pk.v_h_coset_8n = domain_8n.compute_vanishing_poly_over_coset(domain.size);
+        }
+    };
+    const int jobs = N_SEL + 2;
+    if (n_threads <= 1) {
+        for (int k = 0; k < jobs; k++) one(k);
+    } else {
+        std::atomic<int> next(0);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_threads && t < (unsigned)jobs; t++)
+            pool.emplace_back([&] {
+                for (int k = next++; k < jobs; k = next++) one(k);
+            });
+        for (auto &th : pool) th.join();
     }
-    pk.linear_evaluations = domain_8n.coset_fft(FrVec{fr_zero(), fr_one()});
-    pk.v_h_coset_8n = domain_8n.compute_vanishing_poly_over_coset(domain.size);
     return pk;
 }
 
@@ -435,14 +456,26 @@ struct Prover {  // prover.rs:22-30
     std::vector<size_t> public_input_indexes;
 
     // compiler.rs:152-171: unwrap_or_default for the 11 selectors, `?` for the sigmas
+    // With n_threads > 1 the fifteen commitments run side by side, one thread each (same points: they do not depend
+    // on each other), instead of one after the other with the windows of each spread over the threads.
     int commit_selectors(unsigned n_threads) {
-        for (int k = 0; k < N_SEL; k++) {
-            int rc = ck.commit(pk.poly[k], selector_comms[k], n_threads);
-            if (rc != 0) {
-                if (k >= S1) return rc;
+        int rcs[N_SEL];
+        if (n_threads <= 1) {
+            for (int k = 0; k < N_SEL; k++) rcs[k] = ck.commit(pk.poly[k], selector_comms[k], 1);
+        } else {
+            std::atomic<int> next(0);
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < n_threads && t < (unsigned)N_SEL; t++)
+                pool.emplace_back([&] {
+                    for (int k = next++; k < N_SEL; k = next++) rcs[k] = ck.commit(pk.poly[k], selector_comms[k], 1);
+                });
+            for (auto &th : pool) th.join();
+        }
+        for (int k = 0; k < N_SEL; k++)
+            if (rcs[k] != 0) {
+                if (k >= S1) return rcs[k];
                 selector_comms[k] = g1a_identity();
             }
-        }
         return 0;
     }
 };

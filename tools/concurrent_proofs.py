@@ -1,6 +1,8 @@
 """Throughput of small proofs with several contexts (one per host thread, each with its own stream) on one GPU:
 a 2^16-gate proof is bound by launch and dependency latency, so independent proofs overlap.
-    python tools/concurrent_proofs.py LOG_GATES THREADS [PROOFS_PER_THREAD]"""
+    python tools/concurrent_proofs.py LOG_GATES THREADS [PROOFS_PER_THREAD] [START_AT]
+START_AT (seconds since the epoch) holds the timed loop back until that moment, so that several processes started
+together (each has its own hardware queues) measure over the same window; their rates then add up."""
 import os
 import sys
 import threading
@@ -18,6 +20,7 @@ def main():
     from zkvm_amd import api, circuits
     log_n, threads = int(sys.argv[1]), int(sys.argv[2])
     per_thread = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    start_at = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
     n = 1 << log_n
     circ = circuits.arithmetic_circuit(n, seed=3)
     workers = []
@@ -41,6 +44,9 @@ def main():
     for k in range(threads):
         run(k, 2)                       # warm-up, serially
     ts = [threading.Thread(target=run, args=(k, per_thread)) for k in range(threads)]
+    if start_at:
+        assert time.time() < start_at, "set up too late for the common start"
+        time.sleep(start_at - time.time())
     t0 = time.perf_counter()
     for t in ts:
         t.start()
@@ -49,8 +55,9 @@ def main():
     elapsed = time.perf_counter() - t0
     assert all(d == digests[0] for d in digests), "proofs differ between contexts"
     total = threads * per_thread
-    print("2^%d gates, %d threads: %d proofs in %.3f s -> %.1f proofs/s (%.2f ms per proof per thread)"
-          % (log_n, threads, total, elapsed, total / elapsed, elapsed / per_thread * 1e3), flush=True)
+    print("2^%d gates, %d threads: %d proofs in %.3f s -> %.1f proofs/s (%.2f ms per proof per thread)%s"
+          % (log_n, threads, total, elapsed, total / elapsed, elapsed / per_thread * 1e3,
+             "  [window %.3f .. %.3f]" % (start_at, start_at + elapsed) if start_at else ""), flush=True)
     for ctx, _, _ in workers:
         ctx.close()
 

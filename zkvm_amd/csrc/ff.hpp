@@ -207,18 +207,21 @@ struct Fp_ {
         constexpr int W = N / 2;
         typedef unsigned __int128 u128;
         uint64_t x[W], y[W], p[W];
-        for (int i = 0; i < W; i++) {
-            x[i] = a.v[2 * i] | (uint64_t)a.v[2 * i + 1] << 32;
-            y[i] = b.v[2 * i] | (uint64_t)b.v[2 * i + 1] << 32;
-            p[i] = P::mod(2 * i) | (uint64_t)P::mod(2 * i + 1) << 32;
-        }
-        uint64_t inv = 1;   // 1 / p mod 2^64 by Newton's iteration (the correct bits double each time), then negated
-        for (int k = 0; k < 6; k++) inv *= 2 - p[0] * inv;
+        __builtin_memcpy(x, a.v, sizeof x);   // the host is little-endian: two 32-bit limbs are one 64-bit word
+        __builtin_memcpy(y, b.v, sizeof y);
+#pragma unroll
+        for (int i = 0; i < W; i++) p[i] = P::mod(2 * i) | (uint64_t)P::mod(2 * i + 1) << 32;
+        uint64_t inv = 1;   // 1 / p mod 2^64 by Newton's iteration (the correct bits double each time), then negated:
+#pragma unroll
+        for (int k = 0; k < 6; k++) inv *= 2 - p[0] * inv;   // constants only, folded at compile time
         inv = 0 - inv;
         uint64_t t[W + 2];
+#pragma unroll
         for (int i = 0; i < W + 2; i++) t[i] = 0;
+#pragma unroll
         for (int i = 0; i < W; i++) {
             u128 c = 0;
+#pragma unroll
             for (int j = 0; j < W; j++) {
                 c += (u128)x[j] * y[i] + t[j];
                 t[j] = (uint64_t)c;
@@ -229,6 +232,7 @@ struct Fp_ {
             t[W + 1] = (uint64_t)(c >> 64);
             const uint64_t m = t[0] * inv;
             c = ((u128)m * p[0] + t[0]) >> 64;
+#pragma unroll
             for (int j = 1; j < W; j++) {
                 c += (u128)m * p[j] + t[j];
                 t[j - 1] = (uint64_t)c;
@@ -238,12 +242,19 @@ struct Fp_ {
             t[W - 1] = (uint64_t)c;
             t[W] = t[W + 1] + (uint64_t)(c >> 64);
         }
-        Fp_ r;   // below 2p, and 2p fits the words: both moduli leave the top bit free
+        // below 2p, and 2p fits the words (both moduli leave the top bit free): one conditional subtraction
+        uint64_t d[W], borrow = 0;
+#pragma unroll
         for (int i = 0; i < W; i++) {
-            r.v[2 * i] = (uint32_t)t[i];
-            r.v[2 * i + 1] = (uint32_t)(t[i] >> 32);
+            const u128 diff = (u128)t[i] - p[i] - borrow;
+            d[i] = (uint64_t)diff;
+            borrow = (uint64_t)(diff >> 64) & 1;
         }
-        return reduce_once(r);
+#pragma unroll
+        for (int i = 0; i < W; i++) d[i] = borrow ? t[i] : d[i];
+        Fp_ r;
+        __builtin_memcpy(r.v, d, sizeof d);
+        return r;
     }
 #endif
     FF_HD static Fp_ mul(const Fp_ &a, const Fp_ &b) {

@@ -25,7 +25,13 @@
 #include "msm.hpp"
 #include "fq28.hpp"
 #include <cmath>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 namespace zk {
@@ -1081,7 +1087,69 @@ __global__ void __launch_bounds__(256) msm_powers_kernel(Fr tau, G1Affine g, uin
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// MAX_BATCH - 1 host threads that sleep between batches.  run(m, f) has f(1) .. f(m - 1) done by them while the caller
+// does f(0), and returns when all are done.  One caller at a time (the engine's owner serialises its calls).
+struct MsmEngine::TailPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    const std::function<void(uint32_t)> *job = nullptr;
+    uint64_t generation = 0;
+    uint32_t count = 0;
+    std::atomic<uint32_t> done{0};
+    bool stop = false;
+    std::thread workers[MAX_BATCH - 1];
+    uint32_t n_workers = 0;
+
+    TailPool() {
+        try {
+            for (; n_workers < MAX_BATCH - 1; n_workers++) workers[n_workers] = std::thread([this, id = n_workers + 1] { loop(id); });
+        } catch (const std::system_error &) {
+            shut_down();
+            throw;
+        }
+    }
+    ~TailPool() { shut_down(); }
+    void shut_down() {
+        {
+            std::lock_guard<std::mutex> hold(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (uint32_t i = 0; i < n_workers; i++) workers[i].join();
+        n_workers = 0;
+    }
+    void loop(uint32_t id) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(uint32_t)> *f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+                if (id >= count) continue;   // a batch smaller than the pool
+                f = job;
+            }
+            (*f)(id);
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void run(uint32_t m, const std::function<void(uint32_t)> &f) {
+        {
+            std::lock_guard<std::mutex> hold(mu);
+            job = &f;
+            count = m;
+            done.store(0, std::memory_order_relaxed);
+            generation++;
+        }
+        cv.notify_all();
+        f(0);
+        while (done.load(std::memory_order_acquire) < m - 1) std::this_thread::yield();   // tens of microseconds at most
+    }
+};
+
 MsmEngine::~MsmEngine() {
+    delete tail_pool_;
     DevBuf *all[] = {&points_, &counts_, &offsets_, &cursor_, &sorted_, &buckets_, &block_sums_, &tasks_, &partials_,
                      &misc_,   &seg_,    &group_sums_, &order_, &digits_, &table28_, &range_cnt_, &mid_, &slice_tasks_};
     for (DevBuf *b : all) b->release();
@@ -1564,12 +1632,12 @@ void MsmEngine::enqueue_result_copy(uint32_t m, uint32_t groups) {
 }
 void MsmEngine::finish_host(uint32_t m, uint32_t groups, uint32_t log_seg, G1Proj *out) {
     const G1Proj *all = reinterpret_cast<const G1Proj *>(static_cast<const char *>(host_sums_) + 64);
-    for (uint32_t j = 0; j < m; j++) {
+    auto one = [&](uint32_t j) {
         const G1Proj *gs = all + (size_t)j * groups;
         // sum_b (b+1) bucket_b = sum_s W_s + L * sum_k 2^k Q_k + sum_s T_s (group layout: msm_group_partial_kernel)
         if (groups == 2) {
             out[j] = g1_add(gs[0], gs[1]);
-            continue;
+            return;
         }
         const uint32_t n_bits = groups - 3;
         G1Proj total = G1Proj::identity();
@@ -1581,6 +1649,22 @@ void MsmEngine::finish_host(uint32_t m, uint32_t groups, uint32_t log_seg, G1Pro
         total = g1_add(total, g1_add(gs[n_bits - 1], gs[n_bits]));
         total = g1_add(total, g1_add(gs[n_bits + 1], gs[n_bits + 2]));
         out[j] = total;
+    };
+    // A sum's chain of some forty dependent curve operations is twenty microseconds of host work while the GPU waits:
+    // the sums of a batch are added up side by side by threads that sleep between batches (starting a thread per sum
+    // would cost as much as the chain itself).
+    if (m > 1 && groups > 2 && !tail_pool_ && !tail_pool_failed_) {
+        try {
+            tail_pool_ = new TailPool();
+        } catch (const std::exception &) {   // no threads to be had: the sums are added one after the other
+            tail_pool_failed_ = true;
+        }
+    }
+    if (m > 1 && groups > 2 && tail_pool_) {
+        const std::function<void(uint32_t)> f = one;
+        tail_pool_->run(m, f);
+    } else {
+        for (uint32_t j = 0; j < m; j++) one(j);
     }
 }
 void MsmEngine::finish_batch(uint32_t m, uint32_t groups, uint32_t log_seg, G1Proj *out) {

@@ -87,6 +87,9 @@ class MsmEngine {
     void *host_sums_ = nullptr;   // pinned: 64 scratch bytes, then MAX_BATCH * MAX_GROUPS group sums
     static const uint32_t MAX_GROUPS = 40;
     void ensure_pinned();
+    struct TailPool;              // host threads that add up the group sums of a batch side by side (finish_host)
+    TailPool *tail_pool_ = nullptr;
+    bool tail_pool_failed_ = false;
 };
 
 }  // namespace zk

@@ -1,6 +1,6 @@
 """Where one step of a workload spends its time on the GPU, from a rocprofv3 kernel trace.
 
-    python tools/timeline_gaps.py <kernel_trace.csv> [first_kernel_of_a_step]
+    python tools/timeline_gaps.py <kernel_trace.csv> [first_kernel_of_a_step] [--list]
 
 Takes the last complete step in the trace (from one launch of `first_kernel_of_a_step` to the next; default: the
 row-wise gate check, which opens a proof), and prints the kernels in launch order with the idle time in front of each
@@ -9,8 +9,10 @@ import csv
 import sys
 from collections import defaultdict
 
-path = sys.argv[1]
-first = sys.argv[2] if len(sys.argv) > 2 else "gate_check_kernel"
+listing = "--list" in sys.argv      # also print every launch of the step: gap before it, duration, name
+argv = [a for a in sys.argv if a != "--list"]
+path = argv[1]
+first = argv[2] if len(argv) > 2 else "gate_check_kernel"
 rows = []
 for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
@@ -44,5 +46,12 @@ for name, (ns, cnt) in sorted(per.items(), key=lambda kv: -kv[1][0]):
 print("\nlargest idle gaps (before kernel):")
 for gap, name in sorted(gaps, reverse=True)[:25]:
     print("  %8.1f us  before %s" % (gap / 1e3, name))
+if listing:
+    print("\nlaunches in order (gap before, duration, kernel):")
+    prev_end = step[0][0]
+    for s, e, name in step:
+        short = name.split("(")[0].split("<")[0].replace("zk::", "").replace("void ", "")
+        print("  %7.1f us %8.1f us  %s" % (max(s - prev_end, 0) / 1e3, (e - s) / 1e3, short))
+        prev_end = max(prev_end, e)
 print("\nsum of gaps above 20 us: %.3f ms; of gaps below: %.3f ms"
       % (sum(g for g, _ in gaps if g > 20000) / 1e6, sum(g for g, _ in gaps if g <= 20000) / 1e6))

@@ -1578,6 +1578,10 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     if (top_bits < log_B) chain += (max_items / K) >> top_bits;
     // four lanes at most unless the buckets are so few that even eight or sixteen lanes each leave the chip unfilled
     while (log_B <= 15 && (chain >> log_p) >= 6 && (log_p < 2 || (log_p < 4 && ((uint64_t)m * B << log_p) < 65536))) log_p++;
+    // ... and no more lanes in total than fill the chip 4/3 times over (4096 waves): the joining additions at the end
+    // (a full addition per halving, executed by the whole wave) are then dearer than the chains they shorten (2^15-gate
+    // proof, four sums per launch: 3.88 ms with four lanes per bucket, 3.77 with two, 4.12 with one)
+    while (log_p > 0 && ((uint64_t)m * B << log_p) > 262144) log_p--;
     {
         const dim3 grid(ceil_div((uint64_t)B << log_p, 256), fused ? m : 1);
         for (uint32_t j = 0; j < (fused ? 1u : m); j++) {

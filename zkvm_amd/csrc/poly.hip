@@ -470,14 +470,19 @@ struct EvalJobDev {
 
 // Thread t of the job sums c[t + m*STRIDE] * (x^STRIDE)^m by Horner (coalesced loads), scales by x^t, and the
 // block adds its 256 values.
-__global__ void __launch_bounds__(256) eval_partial_kernel(const EvalJobDev *jobs, Fr *partials) {
+// The jobs of a launch travel as a kernel argument: no staging copy, and no wait for one, in front of the launch.
+static const int EVAL_JOBS_PER_LAUNCH = 16;
+struct EvalJobs {
+    EvalJobDev j[EVAL_JOBS_PER_LAUNCH];
+};
+__global__ void __launch_bounds__(256) eval_partial_kernel(const EvalJobs jobs, Fr *partials) {
     __shared__ uint32_t sh[2 * SCAN_T * 8];
-    const EvalJobDev *job = jobs + blockIdx.y;
+    const EvalJobDev *job = &jobs.j[blockIdx.y];
     const uint64_t len = job->len;
     const uint32_t t = blockIdx.x * EVAL_T + threadIdx.x;
     Fr acc = Fr::zero();
     if (t < len) {
-        const Fr xs = ld(&job->x_stride);
+        const Fr xs = job->x_stride;
         uint64_t m = (len - 1 - t) / EVAL_STRIDE;  // highest multiple with t + m*STRIDE < len
         const Fr *p = job->coeffs + t;
         acc = ld(p + m * EVAL_STRIDE);
@@ -485,7 +490,7 @@ __global__ void __launch_bounds__(256) eval_partial_kernel(const EvalJobDev *job
             m--;
             acc = Fr::add(Fr::mul(acc, xs), ld(p + m * EVAL_STRIDE));
         }
-        if (t) acc = Fr::mul(acc, Fr::pow_u64(ld(&job->x), t));
+        if (t) acc = Fr::mul(acc, Fr::pow_u64(job->x, t));
     }
     Fr total;
     (void)block_exclusive<OpAdd>(sh, acc, &total);
@@ -505,20 +510,21 @@ __global__ void __launch_bounds__(64) eval_final_kernel(const Fr *partials, Fr *
 
 void PolyEngine::evaluate(const EvalJob *jobs, int n_jobs, Fr *out_dev) {
     if (n_jobs <= 0) return;
-    std::vector<EvalJobDev> h(n_jobs);
-    for (int j = 0; j < n_jobs; j++) {
-        h[j].coeffs = jobs[j].coeffs;
-        h[j].len = jobs[j].len;
-        h[j].x = jobs[j].x;
-        h[j].x_stride = Fr::pow_u64(jobs[j].x, EVAL_STRIDE);
+    jobs_.reserve((size_t)n_jobs * EVAL_BLOCKS * sizeof(Fr));
+    Fr *partials = jobs_.as<Fr>();
+    for (int first = 0; first < n_jobs; first += EVAL_JOBS_PER_LAUNCH) {
+        const int count = n_jobs - first < EVAL_JOBS_PER_LAUNCH ? n_jobs - first : EVAL_JOBS_PER_LAUNCH;
+        EvalJobs h;
+        for (int j = 0; j < count; j++) {
+            h.j[j].coeffs = jobs[first + j].coeffs;
+            h.j[j].len = jobs[first + j].len;
+            h.j[j].x = jobs[first + j].x;
+            h.j[j].x_stride = Fr::pow_u64(jobs[first + j].x, EVAL_STRIDE);
+        }
+        for (int j = count; j < EVAL_JOBS_PER_LAUNCH; j++) h.j[j] = h.j[0];
+        hipLaunchKernelGGL(eval_partial_kernel, dim3(EVAL_BLOCKS, count), dim3(EVAL_T), 0, stream_, h,
+                           partials + (size_t)first * EVAL_BLOCKS);
     }
-    const size_t job_bytes = (size_t)n_jobs * sizeof(EvalJobDev);
-    jobs_.reserve(job_bytes + (size_t)n_jobs * EVAL_BLOCKS * sizeof(Fr));
-    Fr *partials = reinterpret_cast<Fr *>(jobs_.as<char>() + job_bytes);
-    // the staging vector is a host temporary: finish the copy before it goes out of scope
-    ZK_HIP(hipMemcpyAsync(jobs_.p, h.data(), job_bytes, hipMemcpyHostToDevice, stream_));
-    ZK_HIP(hipStreamSynchronize(stream_));
-    hipLaunchKernelGGL(eval_partial_kernel, dim3(EVAL_BLOCKS, n_jobs), dim3(EVAL_T), 0, stream_, jobs_.as<EvalJobDev>(), partials);
     hipLaunchKernelGGL(eval_final_kernel, dim3(n_jobs), dim3(64), 0, stream_, partials, out_dev);
     ZK_HIP(hipGetLastError());
 }

@@ -703,6 +703,44 @@ void PolyEngine::patch(Fr *p, const uint64_t *idx, const Fr *vals, const bool *s
     ZK_HIP(hipGetLastError());
 }
 
+// ---- the quotient's four pieces -------------------------------------------------------------------------------
+struct SplitArgs {
+    Fr *t, *low, *mid, *high;
+    uint64_t n;
+    Fr b[3];
+};
+__global__ void __launch_bounds__(256) split_quotient_kernel(SplitArgs a) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n = a.n;
+    if (i < n) {
+        st(a.low + i, ld(a.t + i));
+    } else if (i < 2 * n) {
+        Fr v = ld(a.t + i);
+        if (i == n) v = Fr::sub(v, a.b[0]);
+        st(a.mid + (i - n), v);
+    } else if (i < 3 * n) {
+        Fr v = ld(a.t + i);
+        if (i == 2 * n) v = Fr::sub(v, a.b[1]);
+        st(a.high + (i - 2 * n), v);
+    } else if (i == 3 * n) {
+        st(a.low + n, a.b[0]);
+        st(a.mid + n, a.b[1]);
+        st(a.high + n, a.b[2]);
+        st(a.t + 3 * n, Fr::sub(ld(a.t + 3 * n), a.b[2]));
+    }
+}
+void PolyEngine::split_quotient(Fr *t, uint64_t n, Fr *low, Fr *mid, Fr *high, const Fr b[3]) {
+    SplitArgs a;
+    a.t = t;
+    a.low = low;
+    a.mid = mid;
+    a.high = high;
+    a.n = n;
+    for (int k = 0; k < 3; k++) a.b[k] = b[k];
+    hipLaunchKernelGGL(split_quotient_kernel, dim3(ceil_div(3 * n + 1, 256)), dim3(256), 0, stream_, a);
+    ZK_HIP(hipGetLastError());
+}
+
 // ---- scatter -------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) scatter_kernel(Fr *dst, const uint64_t *idx, const Fr *vals, uint32_t count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -763,11 +801,21 @@ void PolyEngine::to_canonical(const Fr *in, uint64_t count, Fr *out_raw) {
 }
 
 // ---- degree -------------------------------------------------------------------------------------------------
-// *out = 1 + index of the highest non-zero coefficient (0 for the zero polynomial)
-__global__ void __launch_bounds__(1024) degree_kernel(const Fr *coeffs, uint64_t len, unsigned long long *out) {
+// out[j] = 1 + index of the highest non-zero coefficient of vector j (0 for the zero polynomial); the vectors of a
+// commitment batch share one launch (blockIdx.y = j)
+struct DegreeJobs {
+    const Fr *coeffs[8];
+    uint64_t len[8];
+};
+__global__ void __launch_bounds__(1024) degree_kernel(const DegreeJobs jobs, unsigned long long *out_all) {
     __shared__ unsigned long long wave_max[16];
+    const Fr *coeffs = jobs.coeffs[blockIdx.y];
+    const uint64_t len = jobs.len[blockIdx.y];
+    unsigned long long *out = out_all + blockIdx.y;
+    const uint64_t n_blocks = (len + 4095) / 4096;
+    if (blockIdx.x >= n_blocks) return;   // a shorter vector of the batch
     // blocks walk the vector from the top, so the block holding the leading coefficient is among the first to run
-    const uint64_t block_from_top = gridDim.x - 1 - blockIdx.x;
+    const uint64_t block_from_top = n_blocks - 1 - blockIdx.x;
     const uint64_t base = block_from_top * 4096 + threadIdx.x;
     // a block above has found a coefficient already: nothing down here can raise the result (one thread reads, so
     // that the whole workgroup takes the same way)
@@ -799,9 +847,14 @@ void PolyEngine::lengths_enqueue(uint32_t m, const Fr *const *coeffs, const uint
     jobs_.reserve(64);
     unsigned long long *d = jobs_.as<unsigned long long>();
     ZK_HIP(hipMemsetAsync(d, 0, 8 * m, stream_));
-    for (uint32_t j = 0; j < m; j++)
-        if (lens[j])
-            hipLaunchKernelGGL(degree_kernel, dim3(ceil_div(lens[j], 4096)), dim3(1024), 0, stream_, coeffs[j], lens[j], d + j);
+    DegreeJobs jobs;
+    uint64_t longest = 0;
+    for (uint32_t j = 0; j < 8; j++) {
+        jobs.coeffs[j] = j < m ? coeffs[j] : nullptr;
+        jobs.len[j] = j < m ? lens[j] : 0;
+        if (jobs.len[j] > longest) longest = jobs.len[j];
+    }
+    if (longest) hipLaunchKernelGGL(degree_kernel, dim3(ceil_div(longest, 4096), m), dim3(1024), 0, stream_, jobs, d);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipMemcpyAsync(host_out, d, 8 * m, hipMemcpyDeviceToHost, stream_));
 }

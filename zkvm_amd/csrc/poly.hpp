@@ -82,6 +82,11 @@ class PolyEngine {
     void ruffini(const Fr *coeffs, uint64_t len, const Fr &root, Fr *out);
     // small edits of single coefficients: p[idx] = p[idx] - v (sub = true) or p[idx] = v
     void patch(Fr *p, const uint64_t *idx, const Fr *vals, const bool *sub, int count);
+    // The quotient's split into its four committed pieces with their blinders (plonk/src/compiler/prover.rs:327-351) in
+    // one pass: low / mid / high = t[0, n), t[n, 2n), t[2n, 3n) copied out with room for one more coefficient,
+    //   low.push(b[0]);  mid[0] -= b[0], mid.push(b[1]);  high[0] -= b[1], high.push(b[2]);  t[3n] -= b[2]
+    // (the fourth piece stays where it is, from t + 3n)
+    void split_quotient(Fr *t, uint64_t n, Fr *low, Fr *mid, Fr *high, const Fr b[3]);
 
     // number of coefficients once leading zeros are dropped (Polynomial::truncate_leading_zeros,
     // plonk/src/fft/polynomial.rs:95-103); synchronises the stream

@@ -1241,24 +1241,11 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     // prover.rs:327-351: the reference slices t[3n..] and indexes t_fourth[0]; both panic when t is shorter
     if (t_len < 3 * n + 1) return ZKGPU_ERR_QUOTIENT_SHAPE;
     const uint64_t t4_len = t_len - 3 * n;
-    ZK_HIP(hipMemcpyAsync(t_low, t, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream_));
-    ZK_HIP(hipMemcpyAsync(t_mid, t + n, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream_));
-    ZK_HIP(hipMemcpyAsync(t_high, t + 2 * n, n * sizeof(Fr), hipMemcpyDeviceToDevice, stream_));
     Fr *t_fourth = t + 3 * n;
     {
-        const Fr b12 = bl[11], b13 = bl[12], b14 = bl[13];
-        uint64_t i1[1] = {n};
-        bool set1[1] = {false};
-        poly_.patch(t_low, i1, &b12, set1, 1);  // t_low.push(b_12)
-        uint64_t i2[2] = {0, n};
-        Fr v2[2] = {b12, b13};
-        bool s2[2] = {true, false};
-        poly_.patch(t_mid, i2, v2, s2, 2);  // t_mid[0] -= b_12 ; push(b_13)
-        Fr v3[2] = {b13, b14};
-        poly_.patch(t_high, i2, v3, s2, 2);  // t_high[0] -= b_13 ; push(b_14)
-        uint64_t i4[1] = {0};
-        bool s4[1] = {true};
-        poly_.patch(t_fourth, i4, &b14, s4, 1);  // t_fourth[0] -= b_14
+        // t_low.push(b_12); t_mid[0] -= b_12, push(b_13); t_high[0] -= b_13, push(b_14); t_fourth[0] -= b_14
+        const Fr b[3] = {bl[11], bl[12], bl[13]};
+        poly_.split_quotient(t, n, t_low, t_mid, t_high, b);
     }
     {
         const Fr *cp[4] = {t_low, t_mid, t_high, t_fourth};

@@ -723,6 +723,39 @@ __global__ void msm_schedule_scan_kernel(uint32_t *class_cursor, uint32_t first_
     class_cursor[N_CLASSES] = run;
 }
 
+// The three schedule launches in one, for bucket sets small enough that one workgroup per sum walks all of them
+// (nb <= 2^13): class histogram in LDS, its scan, and the placement.  Leaves `order` and the sum's total in
+// class_cursor[N_CLASSES] (all the accumulation reads of the cursors); needs no cleared cursors.
+__global__ void __launch_bounds__(1024) msm_schedule_small_kernel(const uint32_t *counts, uint32_t nb, uint32_t shift, uint32_t big,
+                                                                  uint32_t *class_cursor, uint32_t *order) {
+    __shared__ uint32_t hist[N_CLASSES + 1];
+    const uint32_t sum = blockIdx.x;
+    counts += (size_t)sum * nb;
+    order += (size_t)sum * nb;
+    class_cursor += (size_t)sum * (N_CLASSES + 1);
+    for (uint32_t t = threadIdx.x; t <= N_CLASSES; t += blockDim.x) hist[t] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) {
+        const uint32_t cnt = counts[i];
+        if (cnt <= big) atomicAdd(&hist[BIG_BUCKET - (cnt >> shift)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {   // 257 entries
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < N_CLASSES; t++) {
+            const uint32_t v = hist[t];
+            hist[t] = run;
+            run += v;
+        }
+        class_cursor[N_CLASSES] = run;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) {
+        const uint32_t cnt = counts[i];
+        if (cnt <= big) order[atomicAdd(&hist[BIG_BUCKET - (cnt >> shift)], 1u)] = i;
+    }
+}
+
 // ---- bucket accumulation ----------------------------------------------------------------------------------
 // 2^LOG_P neighbouring lanes share a bucket: lane `part` adds entries part, part + P, ... and the partial sums
 // meet through lane shuffles.  With fewer buckets than the chip has lanes the launch is bound by the longest chain
@@ -1437,7 +1470,10 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
 
     const G1Table28 *table = table28_.as<G1Table28>();
     ZK_HIP(hipMemsetAsync(task_count, 0, 4, stream_));
-    ZK_HIP(hipMemsetAsync(class_cursor, 0, (size_t)m * (N_CLASSES + 1) * 4, stream_));
+    // up to 2^13 buckets one workgroup per sum schedules faster than three launches (11 against 19 us; at 2^15 buckets
+    // the atomics of a single workgroup on the few busy classes make it slower: 28 us)
+    const bool small_schedule = log_B <= 13;
+    if (!small_schedule) ZK_HIP(hipMemsetAsync(class_cursor, 0, (size_t)m * (N_CLASSES + 1) * 4, stream_));
 
     auto mark = [&](int k) {
         if (profile_) ZK_HIP(hipEventRecord(profile_[k], stream_));
@@ -1561,11 +1597,16 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     }
     mark(5);
     // schedule: class histogram, scan, placement
-    hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024), m), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
-                       class_shift, big, class_cursor, order, 0u);
-    hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(m), dim3(64), 0, stream_, class_cursor, 0u);
-    hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024), m), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
-                       class_shift, big, class_cursor, order, 0u);
+    if (small_schedule) {
+        hipLaunchKernelGGL(msm_schedule_small_kernel, dim3(m), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B, class_shift, big,
+                           class_cursor, order);
+    } else {
+        hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024), m), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
+                           class_shift, big, class_cursor, order, 0u);
+        hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(m), dim3(64), 0, stream_, class_cursor, 0u);
+        hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024), m), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
+                           class_shift, big, class_cursor, order, 0u);
+    }
     mark(6);
     // Up to 2^15 buckets per sum the launch is bound by the longest chain of additions on one lane, not by throughput:
     // the sums of a batch then share one launch, and two or more lanes share each bucket while the chains are worth

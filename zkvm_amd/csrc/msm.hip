@@ -1490,8 +1490,12 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
         const uint32_t k = j < m ? j : 0;   // unused entries repeat sum 0
         const uint64_t n_items = (uint64_t)lens[k] * K;
         uint32_t S = S_max;
-        if (!staged)
-            while (S > 1 && n_items / S < 16384) S >>= 1;  // keep slices long enough to amortise the histogram flush
+        if (!staged) {
+            // keep slices long enough to amortise the histogram flush and the walks over the slices' counters: 2^14 items,
+            // 2^15 from 2^20 items up (2^16- and 2^17-gate proofs 1.2 % and 1.6 % faster than with 2^14)
+            const uint64_t slice_min = n_items >= (1u << 20) ? 32768 : 16384;
+            while (S > 1 && n_items / S < slice_min) S >>= 1;
+        }
         geom[j].n_items = (uint32_t)n_items;
         geom[j].n = (uint32_t)lens[k];
         geom[j].stride = (uint32_t)n_points_;

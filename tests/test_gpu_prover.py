@@ -257,6 +257,50 @@ def test_two_host_threads_share_one_context(ctx, orc, srs):
                 assert np.array_equal(got[f], want[f]), (key, f)
 
 
+def test_contexts_on_several_host_threads(orc, srs):
+    """Independent contexts on one GPU, one host thread each (the way a service overlaps small proofs): every context
+    has its own stream, buffers and host helper threads, and every proof stays equal to the oracle's."""
+    import threading
+    import zkvm_amd
+    from zkvm_amd import api, circuits
+    c = _circuit(orc, 1024, seed=16)
+    n = c["n"]
+    op = orc.Prover(n, c["constraints"], c["selectors"], srs[:n + 7], b"several", c["pi_indexes"], threads=4)
+    assert op.preprocess_rc == 0
+    blinders = [circuits.random_blinders(40 + k) for k in range(3)]
+    wants = [op.prove(c["wires"], c["public_inputs"], bl) for bl in blinders]
+    contexts = [zkvm_amd.Context(0) for _ in range(4)]
+    results, errors = {}, []
+    try:
+        provers = []
+        for cx in contexts:
+            cx.srs_load(srs[:n + 7])
+            provers.append(api.Prover(cx, n, c["constraints"], c["selectors"].reshape(-1, 4), b"several", c["pi_indexes"]))
+
+        def worker(t):
+            try:
+                for rep in range(4):
+                    for k in range(3):
+                        results[(t, rep, k)] = provers[t].prove(c["wires"].reshape(-1, 4), c["public_inputs"], blinders[k])
+            except Exception as e:   # surfaced below
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        for cx in contexts:
+            cx.close()
+    assert not errors, errors
+    assert len(results) == 48
+    for key, got in results.items():
+        want = wants[key[2]]
+        for f in ("challenges", "evals", "comms_inf", "comms"):
+            assert np.array_equal(got[f], want[f]), (key, f)
+
+
 def test_prove_unsatisfied_circuit(ctx, orc, srs):
     """A witness violating a gate leaves a quotient of 8n coefficients; its fourth slice exceeds the SRS and the
     reference's commit returns PolynomialDegreeTooLarge (kzg10/key.rs:91-105)."""

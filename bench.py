@@ -37,10 +37,13 @@ sys.path.insert(0, ROOT)
 
 FR_TOP = np.uint64(0x73eda753299d7d48)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
-# Issue ceiling of v_mad_u64_u32, the instruction every field product is made of: 4.46 cycles per wave-instruction
-# per SIMD at the 2.25-2.27 GHz the chip holds under that load, measured with tools/ubench.hip on all 1024 SIMDs at 8
-# waves per SIMD in launches of 8 ms (profiles/r02_ubench.log; nominal 4 cycles at 2.4 GHz would be 614).
-MAD_PEAK_G = 518.0       # G wave-instructions / s, whole chip
+# Issue ceiling of v_mad_u64_u32, the instruction every field product is made of, measured with tools/ubench.hip on all
+# 1024 SIMDs at 4 and 8 waves per SIMD in launches of 8 ms (profiles/r03_ubench.log): 4.29 cycles per wave-instruction
+# per SIMD at the 2.34-2.36 GHz held under that load when every operand has a register of its own and the carry-out
+# goes to rotating SGPR pairs (4.35-4.5 with the carry-out in vcc) = 559-563 G/s; in the same harness v_fma_f32 with a
+# register of its own per operand issues every 2.4 cycles (the 2-cycle full-rate class), so v_mad_u64_u32 is a
+# half-rate instruction: nominally 4 cycles, 614 G/s at 2.4 GHz.
+MAD_PEAK_G = 563.0       # G wave-instructions / s, whole chip: the best rate measured for the instruction in any form
 # 32 x 32 -> 64-bit multiply-accumulates of one field product on unsaturated limbs (zkvm_amd/csrc/ff.hpp mul_limbs:
 # UN^2 partial products + UN (UN + 1) for the Montgomery reduction)
 FQ28_MADS = 14 * 14 + 14 * 15        # 406
@@ -49,6 +52,9 @@ FR_MADS = 9 * 9 + 9 * 10             # 171
 # (105 + 210 = 0.78 each) and Y3's two products under one reduction (392 + 210 = 1.48).
 PRODUCTS_PER_MIXED_ADD = 6 + 2 * 315 / 406 + 602 / 406
 MADS_PER_MIXED_ADD = PRODUCTS_PER_MIXED_ADD * FQ28_MADS       # 3666
+# The same addition priced independently of this implementation: 11 field products (the reference's add_mixed,
+# coset-bls12_381/src/g1.rs:701-736) of 2 * 12^2 + 12 = 300 32-bit multiply-accumulates each (CIOS on 12 words).
+ALGORITHMIC_MADS_PER_MIXED_ADD = 11 * 300
 PROFILE_ROUND = "r02"
 
 
@@ -341,8 +347,12 @@ def msm_rooflines(ctx, scalars, shard):
     main = {"bound": "valu", "kernel": "msm_accumulate_kernel (%d points, %d-bit signed windows, %d table levels)" % (shard, window, levels),
             "achieved": round(mad_rate, 1), "peak": MAD_PEAK_G, "unit": "G v_mad_u64_u32 wave-instructions/s",
             "frac": round(mad_rate / MAD_PEAK_G, 3),
-            "peak_source": "tools/ubench.hip on this part: 4.46 cycles per wave-instruction per SIMD at the 2.26 GHz held "
-                           "under that load, 1024 SIMDs (profiles/r02_ubench.log)",
+            "frac_algorithmic": round(items * ALGORITHMIC_MADS_PER_MIXED_ADD / 64 / (acc_ms * 1e-3) / 1e9 / MAD_PEAK_G, 3),
+            "frac_note": "frac = multiply-accumulates this kernel issues / ceiling; frac_algorithmic = 11 products x 300 "
+                         "multiply-accumulates per mixed addition (the reference's formulas on 32-bit words) / ceiling",
+            "peak_source": "tools/ubench.hip on this part: v_mad_u64_u32 with a register of its own per operand issues every "
+                           "4.29 cycles per SIMD at the 2.35 GHz held under that load, 1024 SIMDs (profiles/r03_ubench.log; "
+                           "v_fma_f32 in the same harness: 2.4 cycles)",
             "mads_per_mixed_addition": round(MADS_PER_MIXED_ADD), "mixed_additions_per_launch": int(items),
             "valu_busy_frac_pmc": pmc_valu_busy(pmc_file, "msm_accumulate_kernel") if shard & (shard - 1) == 0 else None,
             "avg_launch_ms": round(acc_ms, 4),

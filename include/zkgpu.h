@@ -95,8 +95,12 @@ int zkgpu_ntt_dev(zkgpu_ctx *ctx, const void *in_dev, size_t len_in, void *out_d
  * rejected with ZKGPU_ERR_INVALID_ARG; and the twiddle tables of this mode and size must already be resident
  * (ZKGPU_ERR_NOT_LOADED otherwise): any earlier zkgpu_ntt / zkgpu_ntt_dev call on this context with the same mode at
  * this size (for coset_ifft) or at this or a larger size (the other three modes) leaves them behind.  All contexts on
- * one GPU share that GPU's array: calls that overlap in time on one GPU race, so serialise them (one context's calls
- * already are).  The array is not cleared between calls; every pass overwrites all the elements the next one reads. */
+ * one GPU share that GPU's array, each on a stream of its own: unordered, overlapping calls would race on it, so the
+ * library orders them itself.  One event per device is waited for before the first pass and recorded behind the last
+ * (hipStreamWaitEvent / hipEventRecord on an event made in zkgpu_init: no allocation), so a call from any context on
+ * that GPU starts only when the previous one's passes are done; calls from several threads and contexts are safe and
+ * run one after the other.  The array is not cleared between calls; every pass overwrites all the elements the next
+ * one reads. */
 #define ZKGPU_NOALLOC_MAX_LOG_N 20
 int zkgpu_ntt_dev_noalloc(zkgpu_ctx *ctx, const void *in_dev, size_t len_in, void *out_dev, uint32_t log_n, int mode);
 

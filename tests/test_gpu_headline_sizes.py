@@ -172,6 +172,49 @@ def test_msm_2_24_distinct_points_properties(orc):
         c.close()
 
 
+@pytest.mark.timeout(600)
+def test_msm_2_22_as_eight_range_shards(orc):
+    """The multi-GPU commitment's shape at size: eight contexts, each generating and holding ONLY its own range
+    SRS[g n / 8, (g + 1) n / 8) of 2^22 + 7 tau-powers (as sharding.srs_setup_range does per rank) and summing its slice of
+    the scalars; the eight 144-byte partial sums added in rank order equal the commitment of one context holding all
+    points, and one shard equals the oracle's sum over the same points."""
+    import torch
+    import zkvm_amd
+    from zkvm_amd import circuits, sharding
+    n, world = (1 << 22) + 7, 8
+    tau, g = circuits.seeded_tau(5), circuits.g1_generator_limbs()
+    sc = witness_like(n, 2222)
+    sc[1::3] = M.random_fr_mont(len(sc[1::3]), 2223)
+    whole_ctx = zkvm_amd.Context(0)
+    try:
+        whole_ctx.srs_setup(tau, g, n)
+        want_xy, want_inf = whole_ctx.msm(torch.from_numpy(sc.view(np.int64)).cuda())
+        pts, _ = whole_ctx.srs_export(n)
+    finally:
+        whole_ctx.close()
+    parts = []
+    for rank in range(world):
+        base, count = sharding.shard_range(n, rank, world)
+        c = zkvm_amd.Context(0)
+        try:
+            sharding.srs_setup_range(c, tau, g, base, count)
+            xy, inf = c.srs_export(count)
+            assert not inf.any() and np.array_equal(xy, pts[base:base + count]), rank
+            part = c.msm_partial(torch.from_numpy(sc[base:base + count].view(np.int64)).cuda(), 0)
+            parts.append(part)
+            if rank == 5:
+                sxy, sinf = zkvm_amd.g1_sum_to_affine(part.reshape(1, 18))
+                m = 1 << 17        # the oracle's leg: the shard's first 2^17 points
+                wxy, winf = orc.g1_to_affine(orc.msm(xy[:m], sc[base:base + m], threads=16))
+                head = c.msm_partial(torch.from_numpy(sc[base:base + m].view(np.int64)).cuda(), 0)
+                hxy, hinf = zkvm_amd.g1_sum_to_affine(head.reshape(1, 18))
+                assert hinf == int(winf) and np.array_equal(hxy, wxy)
+        finally:
+            c.close()
+    got_xy, got_inf = sharding.combine(np.stack(parts))
+    assert got_inf == want_inf == 0 and np.array_equal(got_xy, want_xy)
+
+
 @pytest.mark.timeout(900)
 def test_merkle_batch_circuit_2_24_gates_proof_accepted(orc):
     """The reference's largest configuration with its own gate mix: 519 openings of a height-32 Poseidon-Merkle tree in

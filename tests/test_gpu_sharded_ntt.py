@@ -121,13 +121,14 @@ def _merkle_batch(k, height, seed):
     return P.batch_opening_circuit([tree.opening(p) for p in spots], [tree.leaves[p] for p in spots], threads=4)
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,log_n", [(2, 10), (2, 14), (4, 10), (8, 6), (4, "merkle")])
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,log_n", [(2, 10), (2, 14), (4, 10), (8, 6), (4, "merkle"), (8, 14), (4, 17)])
 def test_shared_proof_equals_oracle(tmp_path, orc, world, log_n):
     """zkgpu_set_collective + zkgpu_prover_set_sharding: every rank holds 1 / world of the ProverKey's coset vectors and
     of the SRS, evaluates the quotient on its slice, and all ranks return the oracle's proof.  The "merkle" case is the
     reference's sharded configuration in small: three Poseidon-Merkle openings in one circuit (2^14 rows, three public
-    inputs) on four ranks."""
+    inputs) on four ranks.  (8, 14) is the fold path at size: n + 3 coefficients are more than a rank's 8n / 8 points;
+    (4, 17) a proof whose passes take three launches per transform on every rank."""
     import torch.multiprocessing as mp
     from zkvm_amd import circuits
     if log_n == "merkle":

@@ -29,6 +29,14 @@ using namespace zk;
         uint64_t q0 = a0, q1 = a1, q2 = a2, q3 = a3, q4 = a4, q5 = a5, q6 = a6, q7 = a7;            \
         double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;              \
         uint32_t m = seed | 1;                                                                      \
+        uint32_t x0 = a0 + 100, x1 = a1 + 101, x2 = a2 + 102, x3 = a3 + 103, x4 = a4 + 104, x5 = a5 + 105, x6 = a6 + 106, x7 = a7 + 107; \
+        uint32_t y0 = a0 + 200, y1 = a1 + 201, y2 = a2 + 202, y3 = a3 + 203, y4 = a4 + 204, y5 = a5 + 205, y6 = a6 + 206, y7 = a7 + 207; \
+        uint64_t p0 = q1 + 9, p1 = q2 + 9, p2 = q3 + 9, p3 = q4 + 9, p4 = q5 + 9, p5 = q6 + 9, p6 = q7 + 9, p7 = q0 + 9; \
+        uint64_t u0 = q1 + 5, u1 = q2 + 5, u2 = q3 + 5, u3 = q4 + 5, u4 = q5 + 5, u5 = q6 + 5, u6 = q7 + 5, u7 = q0 + 5; \
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));        \
+        asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7));        \
+        asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7));        \
+        asm volatile("" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7));        \
         double dm = 1.0000001;                                                                      \
         (void)q0; (void)d0; (void)dm; (void)m;                                                      \
         uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();          \
@@ -57,6 +65,34 @@ using namespace zk;
 #define OP_FMA32(k) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a##k) : "v"(m));
 #define OP_MAD32(k) asm volatile("v_mad_u32_u24 %0, %0, %1, %0\n\tv_mul_hi_u32_u24 %0, %0, %1" : "+v"(a##k) : "v"(m));
 
+// Variants with a register of its own for every operand of every copy (x, y: per-copy multiplicands; the plain forms
+// above share the multiplier `m` among the eight copies and read the accumulator twice), the two-source VOP2 encoding
+// of the f32 multiply-add, and the 64-bit multiply-add with its carry-out in eight different SGPR pairs instead of vcc.
+#define OP_FMA32D(k) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a##k) : "v"(x##k), "v"(y##k));
+#define OP_FMAC32(k) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a##k) : "v"(x##k), "v"(y##k));
+#define OP_PKFMA(k) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(q##k) : "v"(p##k), "v"(u##k));
+#define OP_MAD64D(k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q##k) : "v"(x##k), "v"(y##k) : "vcc");
+#define OP_MAD64S(k) asm volatile("v_mad_u64_u32 %0, s[" MAD64S_LO(k) ":" MAD64S_HI(k) "], %1, %2, %0" : "+v"(q##k) : "v"(x##k), "v"(y##k) : "s" MAD64S_LO(k), "s" MAD64S_HI(k));
+#define MAD64S_LO(k) MAD64S_LO_##k
+#define MAD64S_HI(k) MAD64S_HI_##k
+#define MAD64S_LO_0 "20"
+#define MAD64S_HI_0 "21"
+#define MAD64S_LO_1 "22"
+#define MAD64S_HI_1 "23"
+#define MAD64S_LO_2 "24"
+#define MAD64S_HI_2 "25"
+#define MAD64S_LO_3 "26"
+#define MAD64S_HI_3 "27"
+#define MAD64S_LO_4 "28"
+#define MAD64S_HI_4 "29"
+#define MAD64S_LO_5 "30"
+#define MAD64S_HI_5 "31"
+#define MAD64S_LO_6 "32"
+#define MAD64S_HI_6 "33"
+#define MAD64S_LO_7 "34"
+#define MAD64S_HI_7 "35"
+#define OP_MULLOD(k) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(a##k) : "v"(x##k), "v"(y##k));
+
 #define OP_SHR64(k) asm volatile("v_lshrrev_b64 %0, 28, %0" : "+v"(q##k));
 #define OP_AND(k) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a##k) : "v"(m));
 #define OP_ALIGN(k) asm volatile("v_alignbit_b32 %0, %0, %1, 28" : "+v"(a##k) : "v"(m));
@@ -77,6 +113,12 @@ RATE_KERNEL(k_add64, X8(OP_ADD64))
 RATE_KERNEL(k_mad24, X8(OP_MAD24))
 RATE_KERNEL(k_fma64, X8(OP_FMA64))
 RATE_KERNEL(k_fma32, X8(OP_FMA32))
+RATE_KERNEL(k_fma32d, X8(OP_FMA32D))
+RATE_KERNEL(k_fmac32, X8(OP_FMAC32))
+RATE_KERNEL(k_pkfma, X8(OP_PKFMA))
+RATE_KERNEL(k_mad64d, X8(OP_MAD64D))
+RATE_KERNEL(k_mad64s, X8(OP_MAD64S))
+RATE_KERNEL(k_mullod, X8(OP_MULLOD))
 
 template <class F>
 __global__ void k_field_mul(F *out, uint32_t iters) {
@@ -168,7 +210,13 @@ int main() {
     const uint32_t iters = 16384;   // x 32 instructions per wave: several milliseconds per launch
     for (int w = 1; w <= 8; w *= 2) {
         if (run_rate("fma_f32", k_fma32, w, iters)) return 1;
+        if (run_rate("fma_f32_d", k_fma32d, w, iters)) return 1;    // distinct registers for every operand
+        if (run_rate("fmac_f32", k_fmac32, w, iters)) return 1;     // VOP2 encoding (4-byte instruction)
+        if (run_rate("pk_fma_f32", k_pkfma, w, iters)) return 1;
         if (run_rate("mad_u64", k_mad64, w, iters)) return 1;
+        if (run_rate("mad_u64_d", k_mad64d, w, iters)) return 1;    // distinct multiplicands, carry-out in vcc
+        if (run_rate("mad_u64_s", k_mad64s, w, iters)) return 1;    // distinct multiplicands, carry-out in 8 SGPR pairs
+        if (run_rate("mul_lo_d", k_mullod, w, iters)) return 1;
         if (run_rate("mul_lo", k_mullo, w, iters)) return 1;
         if (run_rate("mul_hi", k_mulhi, w, iters)) return 1;
         if (run_rate("add_co", k_add, w, iters)) return 1;

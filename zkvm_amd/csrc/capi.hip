@@ -39,9 +39,15 @@ struct zkgpu_ctx {
 static __device__ __align__(256) uint4 zkgpu_noalloc_scratch[((size_t)1 << ZKGPU_NOALLOC_MAX_LOG_N) * 2];   // 32 bytes per Fr
 static const int MAX_DEVICES = 64;
 static void *g_noalloc_scratch[MAX_DEVICES] = {nullptr};
+// Contexts on one GPU share that GPU's array while each runs on a stream of its own.  Their uses are put in order by
+// one event per device: a call makes its stream wait for the event, launches, and records the event again behind its
+// last pass, all under g_noalloc_lock, so that the next call (from whichever context) waits for exactly the previous
+// one.  Waiting for and recording an existing event allocates nothing.
+static hipEvent_t g_noalloc_done[MAX_DEVICES] = {nullptr};
 static std::mutex g_noalloc_lock;
 
-// With `device` current: the address of this device's copy of the scratch array.
+// With `device` current: the address of this device's copy of the scratch array (looked up, and the device's ordering
+// event created, on the first call for that device).
 static void *noalloc_scratch_for(int device) {
     ZK_REQUIRE(device >= 0 && device < MAX_DEVICES, ZKGPU_ERR_INVALID_ARG, "device id beyond the library's table");
     std::lock_guard<std::mutex> hold(g_noalloc_lock);
@@ -49,6 +55,9 @@ static void *noalloc_scratch_for(int device) {
         void *ptr = nullptr;
         ZK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(zkgpu_noalloc_scratch)));
         ZK_REQUIRE(ptr != nullptr, ZKGPU_ERR_HIP, "hipGetSymbolAddress returned a null scratch address");
+        hipEvent_t ev = nullptr;
+        ZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g_noalloc_done[device] = ev;
         g_noalloc_scratch[device] = ptr;
     }
     return g_noalloc_scratch[device];
@@ -217,6 +226,15 @@ int zkgpu_ntt_dev_noalloc(zkgpu_ctx *ctx, const void *in_dev, size_t len_in, voi
         ZK_REQUIRE(mode >= 0 && mode <= 3, ZKGPU_ERR_INVALID_ARG, "ntt: mode must be 0..3");
         ZK_REQUIRE(log_n <= ZKGPU_NOALLOC_MAX_LOG_N, ZKGPU_ERR_INVALID_ARG,
                    "ntt_dev_noalloc: the transform exceeds the 2^20-element scratch of the allocation-free entry point");
+        // one user of the device's scratch array at a time, in the order the calls arrive (see g_noalloc_done)
+        std::lock_guard<std::mutex> hold(g_noalloc_lock);
+        hipEvent_t done = g_noalloc_done[ctx->device];
+        ZK_HIP(hipStreamWaitEvent(ctx->stream, done, 0));
+        struct RecordOnExit {   // also behind a call that failed half-way: its launched passes still use the array
+            hipEvent_t ev;
+            hipStream_t st;
+            ~RecordOnExit() { (void)hipEventRecord(ev, st); }
+        } record{done, ctx->stream};
         ctx->ntt->transform_no_alloc((NttMode)mode, static_cast<const Fr *>(in_dev), len_in, static_cast<Fr *>(out_dev), log_n,
                                      static_cast<Fr *>(ctx->noalloc_scratch));
     });

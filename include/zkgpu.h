@@ -354,6 +354,20 @@ int zkgpu_prove(zkgpu_ctx *ctx, const uint64_t *wires, const uint64_t *public_in
                 const uint64_t *blinders14, uint64_t *out_comms_xy, uint8_t *out_comms_infinity, uint64_t *out_evals15,
                 uint64_t *out_challenges10, float *timings8);
 
+/* The reference's service proves one fresh witness after the other (merkle-plonk/src/lib.rs:275-332: one opening
+ * per proof).  zkgpu_witness_prefetch starts the upload of a COMING proof's witness (4 x n values in host memory) on a
+ * copy stream of the context's own, into one of two device buffers, and returns at once; the zkgpu_prove call that is
+ * later given the same `wires` pointer reads the uploaded copy instead of copying itself.  Called right before
+ * zkgpu_prove(witness i) with witness i + 1, the upload (128 MiB at 2^20 gates) runs beside proof i.  The host buffer
+ * should be pinned (zkgpu_host_alloc, or the caller's own hipHostMalloc / hipHostRegister): from pageable memory the
+ * copy is staged by the runtime and the call returns only when it is done.  At most two uploads are outstanding (a
+ * third reuses the older buffer); the host values must stay unchanged until the proof that consumes them has
+ * returned.  No counterpart in the reference (it has no device). */
+int zkgpu_witness_prefetch(zkgpu_ctx *ctx, const uint64_t *wires_host);
+/* Pinned host memory for witnesses (hipHostMalloc); NULL when the allocation fails. */
+void *zkgpu_host_alloc(size_t bytes);
+void zkgpu_host_free(void *p);
+
 /* ---- circuit front-end of the reference's own workload (host only, no context) --------------------------------------
  * OpeningCircuit (merkle-plonk/src/lib.rs:117-131) over opening_gadget (poseidon-merkle/src/zk.rs:16-102) and the
  * Hades permutation gadget (coset-poseidon/src/hades/permutation/gadget.rs:39-106), built gate by gate as the

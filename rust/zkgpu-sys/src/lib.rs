@@ -132,6 +132,9 @@ extern "C" {
     pub fn zkgpu_prove(ctx: *mut zkgpu_ctx, wires: *const u64, public_inputs: *const u64, n_pi: usize,
                        blinders14: *const u64, out_comms_xy: *mut u64, out_comms_infinity: *mut u8,
                        out_evals15: *mut u64, out_challenges10: *mut u64, timings8: *mut f32) -> c_int;
+    pub fn zkgpu_witness_prefetch(ctx: *mut zkgpu_ctx, wires_host: *const u64) -> c_int;
+    pub fn zkgpu_host_alloc(bytes: usize) -> *mut c_void;
+    pub fn zkgpu_host_free(p: *mut c_void);
     pub fn zkgpu_merkle_batch_circuit_size(height: u32, k: u32, constraints: *mut u64, n: *mut u64) -> c_int;
     pub fn zkgpu_merkle_batch_circuit(height: u32, k: u32, leaves: *const u64, branches: *const u64, positions: *const u8,
                                       roots: *const u64, arc: *const u64, mds: *const u64, tag: *const u64, n: u64,

@@ -214,6 +214,52 @@ def test_prove_twice_same_key(ctx, orc, srs):
         assert np.array_equal(got["comms"], want["comms"]) and np.array_equal(got["evals"], want["evals"])
 
 
+def test_prefetched_witnesses(ctx, orc, srs):
+    """zkgpu_witness_prefetch: the loop of the reference's service (a fresh witness per proof,
+    merkle-plonk/src/lib.rs:275-332) with witness i + 1 uploaded beside proof i from two pinned host buffers; every
+    proof equals the oracle's for its own witness and public input, also when an upload is never consumed."""
+    from zkvm_amd import api, circuits
+    n = 1 << 10
+    c = _circuit(orc, n, seed=31)
+    gp, op = _provers(ctx, orc, srs, c)
+    # gate 0 reads q_l * a + PI = 0 and its left wire is tied to nothing else: a witness per value of a[0]
+    witnesses = []
+    for k in range(4):
+        w = c["wires"].copy()
+        pub = c["public_inputs"].copy()
+        if k:
+            v = int(circuits.limbs_to_ints(M.random_fr_mont(1, 900 + k))[0])
+            w[0, 0] = circuits.ints_to_limbs([v])[0]
+            pub = circuits.ints_to_limbs([(circuits.R_MOD - v) % circuits.R_MOD])
+        witnesses.append((w, pub, circuits.random_blinders(50 + k)))
+    want = [op.prove(w, pub, bl) for w, pub, bl in witnesses]
+    assert all(p["rc"] == 0 for p in want) and not np.array_equal(want[0]["comms"][0], want[1]["comms"][0])
+    pins = [api.PinnedFr(4 * n) for _ in range(2)]
+    try:
+        pins[0].array[:] = witnesses[0][0].reshape(-1, 4)
+        gp.prefetch(pins[0].array)
+        for i, (w, pub, bl) in enumerate(witnesses):
+            if i + 1 < len(witnesses):
+                pins[(i + 1) & 1].array[:] = witnesses[i + 1][0].reshape(-1, 4)   # proof i - 1, which read it, has returned
+                gp.prefetch(pins[(i + 1) & 1].array)
+            got = gp.prove(pins[i & 1].array, pub, bl)
+            for key in ("comms", "comms_inf", "evals", "challenges"):
+                assert np.array_equal(got[key], want[i][key]), (i, key)
+        # an upload nobody consumes, then a proof from another (pageable) array and one from a device tensor
+        gp.prefetch(pins[0].array)
+        w, pub, bl = witnesses[2]
+        got = gp.prove(np.ascontiguousarray(w.reshape(-1, 4)), pub, bl)
+        assert np.array_equal(got["comms"], want[2]["comms"]) and np.array_equal(got["evals"], want[2]["evals"])
+        import torch
+        wd = torch.from_numpy(w.reshape(-1, 4).view(np.int64)).cuda()
+        got = gp.prove(wd, pub, bl)
+        assert np.array_equal(got["comms"], want[2]["comms"]) and np.array_equal(got["evals"], want[2]["evals"])
+        ctx.sync()
+    finally:
+        for p in pins:
+            p.close()
+
+
 def test_two_host_threads_share_one_context(ctx, orc, srs):
     """Prover::prove takes &self (compiler/prover.rs:21,210): several host threads may prove with one prover.  The
     library serialises calls on a context, so concurrent proofs and transforms on one context stay exact."""

@@ -98,6 +98,9 @@ SIGNATURES = {
     "zkgpu_linearization": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "zkgpu_aggregate_witness": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.POINTER(C.c_size_t)]),
     "zkgpu_prove": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, _P, _P, _P]),
+    "zkgpu_witness_prefetch": (C.c_int, [_P, _P]),
+    "zkgpu_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "zkgpu_host_free": (None, [_P]),
     "zkgpu_merkle_batch_circuit_size": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "zkgpu_merkle_batch_circuit": (C.c_int, [C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, _P, C.c_uint64, _P, _P, _P, _P, _P,
                                              C.c_uint32]),

@@ -495,6 +495,13 @@ class Prover:
             C.byref(r_len)))
         return out[:r_len.value].copy()
 
+    def prefetch(self, wires):
+        """zkgpu_witness_prefetch: start the upload of a coming proof's witness (a numpy array, ideally over pinned
+        memory from pinned_fr); the prove() call that is given the same array takes the uploaded copy."""
+        w = _np_u64(wires, 4)
+        assert w.shape[0] == 4 * self.n
+        self.ctx._check(self.ctx._lib.zkgpu_witness_prefetch(self.ctx._h, w.ctypes.data))
+
     def prove(self, wires, public_inputs, blinders14, timings=False):
         if _is_torch(wires):
             assert wires.is_cuda and wires.is_contiguous() and wires.numel() == 16 * self.n
@@ -519,6 +526,31 @@ class Prover:
         if timings:
             out["timings_ms"] = dict(zip(PHASE_NAMES, [float(x) for x in tm]))
         return out
+
+
+class PinnedFr:
+    """`count` Fr elements of pinned host memory (zkgpu_host_alloc) as a numpy (count, 4) uint64 array in `.array`;
+    uploads from it run on the copy engine beside the device's work.  Freed by close() or with the object."""
+
+    def __init__(self, count):
+        self._lib = _lib.lib()
+        self._ptr = self._lib.zkgpu_host_alloc(int(count) * 32)
+        if not self._ptr:
+            raise MemoryError("zkgpu_host_alloc(%d bytes) failed" % (int(count) * 32))
+        buf = (C.c_uint64 * (int(count) * 4)).from_address(self._ptr)
+        self.array = np.frombuffer(buf, dtype=np.uint64).reshape(int(count), 4)
+
+    def close(self):
+        if getattr(self, "_ptr", None):
+            self.array = None
+            self._lib.zkgpu_host_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def perm_z(ctx, wires, sigma_evals, beta, gamma):

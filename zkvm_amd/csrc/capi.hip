@@ -932,6 +932,23 @@ int zkgpu_prove(zkgpu_ctx *ctx, const uint64_t *wires, const uint64_t *public_in
     return rc != 0 ? rc : proof_rc;
 }
 
+int zkgpu_witness_prefetch(zkgpu_ctx *ctx, const uint64_t *wires_host) {
+    return guarded(ctx, [&] { ctx->prover->prefetch_witness(wires_host); });
+}
+
+void *zkgpu_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void zkgpu_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int zkgpu_transcript_challenge(const char *label, const char *msg_label, const uint8_t *msg, size_t msg_len,
                                const char *ch_label, uint8_t *out, size_t out_len) {
     if (!label || !msg_label || !ch_label || (!msg && msg_len) || !out) return ZKGPU_ERR_INVALID_ARG;

@@ -89,11 +89,41 @@ Prover::~Prover() {
     tops_dev_.release();
     if (tops_host_) (void)hipHostFree(tops_host_);
     if (sums_ready_) (void)hipEventDestroy(sums_ready_);
+    if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
+    for (int s = 0; s < 2; s++) {
+        wit_buf_[s].release();
+        if (wit_ready_[s]) (void)hipEventDestroy(wit_ready_[s]);
+        if (wit_consumed_[s]) (void)hipEventDestroy(wit_consumed_[s]);
+    }
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+}
+
+void Prover::prefetch_witness(const uint64_t *wires_host) {
+    ZK_REQUIRE(loaded(), ZKGPU_ERR_NOT_LOADED, "witness_prefetch: no prover key loaded");
+    ZK_REQUIRE(wires_host != nullptr, ZKGPU_ERR_INVALID_ARG, "witness_prefetch: null input");
+    if (!copy_stream_) ZK_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    const int s = wit_next_;
+    wit_next_ ^= 1;
+    if (!wit_ready_[s]) {
+        ZK_HIP(hipEventCreateWithFlags(&wit_ready_[s], hipEventDisableTiming));
+        ZK_HIP(hipEventCreateWithFlags(&wit_consumed_[s], hipEventDisableTiming));
+    }
+    wit_src_[s] = nullptr;
+    const size_t bytes = 4 * (size_t)n_ * sizeof(Fr);
+    if (wit_buf_[s].cap < bytes) {
+        ZK_HIP(hipStreamSynchronize(copy_stream_));   // an upload into the buffer about to be replaced
+        ZK_HIP(hipStreamSynchronize(stream_));        // a proof still reading it
+        wit_buf_[s].reserve(bytes);
+    }
+    ZK_HIP(hipStreamWaitEvent(copy_stream_, wit_consumed_[s], 0));   // no-op until a proof has read this buffer
+    ZK_HIP(hipMemcpyAsync(wit_buf_[s].p, wires_host, bytes, hipMemcpyHostToDevice, copy_stream_));
+    ZK_HIP(hipEventRecord(wit_ready_[s], copy_stream_));
+    wit_src_[s] = wires_host;
 }
 
 size_t Prover::device_bytes() const {
     return polys_.cap + evals_.cap + sigma_.cap + work_.cap + small_.cap + pi_lagrange_.cap + evals4_.cap + sel_h_.cap +
-           tops_dev_.cap;
+           tops_dev_.cap + wit_buf_[0].cap + wit_buf_[1].cap;
 }
 
 const Fr *Prover::key_eval8n(int k) {
@@ -1110,7 +1140,15 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
     // protocol phase 1: wire polynomials (prover.rs:240-269)
     // hipMemcpyDefault: the caller's pointer may be host memory or already resident in HBM
     // (a witness that already lies in this GPU's memory is read where it is: nothing below writes to it)
-    {
+    int wit_slot = -1;   // the prefetched buffer this proof reads, if any
+    for (int s = 0; s < 2; s++)
+        if (wit_src_[s] == wires_host && wit_buf_[s].cap >= 4 * n * sizeof(Fr)) wit_slot = s;
+    if (wit_slot >= 0) {
+        // uploaded by prefetch_witness: the copy ran (or runs) on the copy stream beside the previous proof
+        ZK_HIP(hipStreamWaitEvent(stream_, wit_ready_[wit_slot], 0));
+        wires = wit_buf_[wit_slot].as<Fr>();
+        wit_src_[wit_slot] = nullptr;
+    } else {
         hipPointerAttribute_t attr;
         int current = -1;
         const bool resident = hipPointerGetAttributes(&attr, wires_host) == hipSuccess && attr.type == hipMemoryTypeDevice &&
@@ -1122,6 +1160,13 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
             ZK_HIP(hipMemcpyAsync(wires, wires_host, 4 * n * sizeof(Fr), hipMemcpyDefault, stream_));
         }
     }
+    struct MarkConsumed {   // on every way out: the next upload into the buffer waits for this proof's reads of it
+        hipEvent_t ev;
+        hipStream_t st;
+        ~MarkConsumed() {
+            if (ev) (void)hipEventRecord(ev, st);
+        }
+    } mark_consumed{wit_slot >= 0 ? wit_consumed_[wit_slot] : nullptr, stream_};
     Fr *wp[4] = {p_a, p_b, p_c, p_d};
     for (int k = 0; k < 4; k++) blind_poly(wires + k * n, 1, bl + 2 * k, wp[k]);
     int rc;

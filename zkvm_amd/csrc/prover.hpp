@@ -103,6 +103,14 @@ class Prover {
     int prove(const uint64_t *wires_host, const uint64_t *public_inputs_host, size_t n_pi, const uint64_t *blinders14,
               ProofOut &out, ProveTimings *timings);
 
+    // Starts the upload of a coming proof's witness (4 x n wire values in host memory, pinned for the copy to run
+    // beside the device's work) on a copy stream of the prover's own, into one of two device buffers; returns at once.
+    // The prove() call that is later given the same pointer takes the uploaded copy instead of copying itself.  The
+    // reference proves one fresh witness after the other (merkle-plonk/src/lib.rs:275-332): prefetching witness i + 1
+    // right before prove(witness i) hides its upload behind that proof.  At most two uploads are outstanding (a
+    // third reuses the older buffer); the host values must stay unchanged until the proof that consumes them returns.
+    void prefetch_witness(const uint64_t *wires_host);
+
     size_t device_bytes() const;
 
    private:
@@ -135,6 +143,13 @@ class Prover {
     NttEngine &ntt_;
     MsmEngine &msm_;
     PolyEngine &poly_;
+    // prefetch_witness: two witness buffers filled on copy_stream_; ready = behind the upload, consumed = behind the
+    // last kernel of the proof that read the buffer (the next upload into it waits for that)
+    hipStream_t copy_stream_ = nullptr;
+    DevBuf wit_buf_[2];
+    const uint64_t *wit_src_[2] = {nullptr, nullptr};
+    hipEvent_t wit_ready_[2] = {nullptr, nullptr}, wit_consumed_[2] = {nullptr, nullptr};
+    int wit_next_ = 0;
     ExchangeFn exchange_ = nullptr;
     void *exchange_user_ = nullptr;
     uint64_t shard_base_ = 0, total_points_ = 0;

@@ -554,6 +554,7 @@ def run_prove(args, rank, world, local, device):
     value = (1 if sharded else world) * args.steps / elapsed
     if rank == 0 and not sharded and not args.no_sub_records:
         out["with_h2d"] = prove_with_transfers(prover, circ, blinders, n, proof, 1e3 * elapsed / args.steps, max(args.steps // 2, 4))
+        out["proofs_in_flight"] = proofs_in_flight(prover, wires, circ, blinders, proof, max(args.steps // 2, 4), elapsed / args.steps)
 
     # ---- the other parts of the metric, in the same run -----------------------------------------------------------
     if not args.no_sub_records and not sharded:
@@ -677,6 +678,48 @@ def prove_with_transfers(prover, circ, blinders, n, resident_proof, resident_ms,
             "pinned_prefetch_over_resident": round(overlap_ms / resident_ms, 4),
             "note": "pinned_prefetch: zkgpu_witness_prefetch uploads the next witness on a copy stream beside the current "
                     "proof (two device buffers); never the headline value, which has the witness resident in HBM"}
+
+
+def proofs_in_flight(prover, wires, circ, blinders, resident_proof, steps, one_at_a_time_s):
+    """Two proofs at a time on one GPU: the benchmark's context and a clone of it (zkgpu_ctx_clone: the same SRS table
+    and prover key by reference, a stream and per-proof buffers of its own), one host thread each, `steps` proofs per
+    thread.  Throughput, not the latency of the headline."""
+    import threading
+    ctx = prover.ctx
+    clone = ctx.clone()
+    try:
+        provers = [prover, prover.on(clone)]
+        last, errors = [None, None], []
+
+        def run(t, reps):
+            try:
+                for _ in range(reps):
+                    last[t] = provers[t].prove(wires, circ["public_inputs"], blinders)
+            except Exception as exc:   # noqa: BLE001 - reported by the caller's assert
+                errors.append(exc)
+
+        run(1, 1)                       # the clone's first proof builds its twiddle tables and buffers
+        ctx.sync()
+        clone.sync()
+        threads = [threading.Thread(target=run, args=(t, steps)) for t in range(2)]
+        t0 = time.perf_counter()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        ctx.sync()
+        clone.sync()
+        secs = time.perf_counter() - t0
+        assert not errors, errors
+        for p in last:
+            assert np.array_equal(p["comms"], resident_proof["comms"]) and np.array_equal(p["evals"], resident_proof["evals"])
+        shared = clone.device_bytes_shared()
+        return {"contexts": 2, "proofs_per_s": round(2 * steps / secs, 3), "one_at_a_time_proofs_per_s": round(1.0 / one_at_a_time_s, 3),
+                "steps_per_context": steps, "shared_table_and_key_bytes": shared,
+                "clone_private_bytes": clone.device_bytes() - shared,
+                "note": "the second context is a zkgpu_ctx_clone of the first: SRS table and prover key are held once"}
+    finally:
+        clone.close()
 
 
 CPU_BASELINE_RECORD = "r02_cpu_baseline_prove.json"

@@ -132,6 +132,8 @@ extern "C" {
     pub fn zkgpu_prove(ctx: *mut zkgpu_ctx, wires: *const u64, public_inputs: *const u64, n_pi: usize,
                        blinders14: *const u64, out_comms_xy: *mut u64, out_comms_infinity: *mut u8,
                        out_evals15: *mut u64, out_challenges10: *mut u64, timings8: *mut f32) -> c_int;
+    pub fn zkgpu_ctx_clone(src: *mut zkgpu_ctx, out: *mut *mut zkgpu_ctx) -> c_int;
+    pub fn zkgpu_device_bytes_shared(ctx: *const zkgpu_ctx) -> usize;
     pub fn zkgpu_witness_prefetch(ctx: *mut zkgpu_ctx, wires_host: *const u64) -> c_int;
     pub fn zkgpu_host_alloc(bytes: usize) -> *mut c_void;
     pub fn zkgpu_host_free(p: *mut c_void);

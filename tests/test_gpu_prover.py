@@ -303,6 +303,82 @@ def test_two_host_threads_share_one_context(ctx, orc, srs):
                 assert np.array_equal(got[f], want[f]), (key, f)
 
 
+def test_cloned_contexts_share_table_and_key(orc, srs):
+    """zkgpu_ctx_clone = #[derive(Clone)] Prover (compiler/prover.rs:20-21): clones refer to one SRS table and one prover
+    key on the GPU, prove side by side from their own host threads, survive the context they were cloned from, and fall
+    back to the 8n coset on their own (a violated gate) with the reference's error."""
+    import threading
+    import zkvm_amd
+    from zkvm_amd import api, circuits
+    c = _circuit(orc, 1024, seed=18)
+    n = c["n"]
+    op = orc.Prover(n, c["constraints"], c["selectors"], srs[:n + 7], b"cloned", c["pi_indexes"], threads=4)
+    assert op.preprocess_rc == 0
+    blinders = [circuits.random_blinders(60 + k) for k in range(3)]
+    wants = [op.prove(c["wires"], c["public_inputs"], bl) for bl in blinders]
+    first = zkvm_amd.Context(0)
+    contexts = [first]
+    results, errors = {}, []
+    try:
+        first.srs_load(srs[:n + 7])
+        gp = api.Prover(first, n, c["constraints"], c["selectors"].reshape(-1, 4), b"cloned", c["pi_indexes"])
+        assert first.device_bytes_shared() == 0
+        alone = first.device_bytes()
+        contexts += [first.clone() for _ in range(3)]
+        provers = [gp] + [gp.on(cx) for cx in contexts[1:]]
+        shared = first.device_bytes_shared()
+        # the table (96 + 128 bytes per point and level) and the key's vectors are held once
+        assert shared >= (n + 7) * 96 + 15 * n * 32 and shared <= alone
+        for cx in contexts[1:]:
+            assert cx.device_bytes_shared() == shared and cx.device_bytes() - shared < alone - shared + (1 << 20)
+        sxy, sinf = provers[2].selector_commitments()
+        wxy, winf = op.selector_comms()
+        assert np.array_equal(sinf, winf) and np.array_equal(sxy[winf == 0], wxy[winf == 0])
+
+        def worker(t):
+            try:
+                for rep in range(4):
+                    for k in range(3):
+                        results[(t, rep, k)] = provers[t].prove(c["wires"].reshape(-1, 4), c["public_inputs"], blinders[k])
+            except Exception as e:   # surfaced below
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert len(results) == 48
+        for key, got in results.items():
+            for f in ("challenges", "evals", "comms_inf", "comms"):
+                assert np.array_equal(got[f], wants[key[2]][f]), (key, f)
+            assert got["coset"] == 4
+        # the source loads another key and is then destroyed: the clones keep the table and key they refer to
+        c2 = _circuit(orc, 256, seed=19)
+        first.srs_load(srs[:256 + 7])
+        other = api.Prover(first, 256, c2["constraints"], c2["selectors"].reshape(-1, 4), b"other", c2["pi_indexes"])
+        op2 = orc.Prover(256, c2["constraints"], c2["selectors"], srs[:256 + 7], b"other", c2["pi_indexes"], threads=4)
+        got2, want2 = other.prove(c2["wires"].reshape(-1, 4), c2["public_inputs"], blinders[0]), op2.prove(c2["wires"], c2["public_inputs"], blinders[0])
+        assert np.array_equal(got2["comms"], want2["comms"]) and np.array_equal(got2["evals"], want2["evals"])
+        first.close()
+        got = provers[3].prove(c["wires"].reshape(-1, 4), c["public_inputs"], blinders[1])
+        assert np.array_equal(got["comms"], wants[1]["comms"]) and np.array_equal(got["evals"], wants[1]["evals"])
+        # a violated gate on a clone: the proof runs over the 8n coset (vectors the clone builds for itself) and ends in
+        # the oracle's error; the next good proof is exact again
+        bad = c["wires"].copy()
+        bad[2, 5, 0] ^= np.uint64(1)
+        want_bad = op.prove(bad, c["public_inputs"], blinders[2])
+        assert want_bad["rc"] == 2
+        with pytest.raises(api.PolynomialDegreeTooLarge):
+            provers[1].prove(bad.reshape(-1, 4), c["public_inputs"], blinders[2])
+        got = provers[1].prove(c["wires"].reshape(-1, 4), c["public_inputs"], blinders[2])
+        assert np.array_equal(got["comms"], wants[2]["comms"]) and np.array_equal(got["evals"], wants[2]["evals"])
+    finally:
+        for cx in contexts:
+            cx.close()
+
+
 def test_contexts_on_several_host_threads(orc, srs):
     """Independent contexts on one GPU, one host thread each (the way a service overlaps small proofs): every context
     has its own stream, buffers and host helper threads, and every proof stays equal to the oracle's."""

@@ -98,6 +98,8 @@ SIGNATURES = {
     "zkgpu_linearization": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "zkgpu_aggregate_witness": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, C.POINTER(C.c_size_t)]),
     "zkgpu_prove": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P, _P, _P, _P, _P]),
+    "zkgpu_ctx_clone": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "zkgpu_device_bytes_shared": (C.c_size_t, [_P]),
     "zkgpu_witness_prefetch": (C.c_int, [_P, _P]),
     "zkgpu_host_alloc": (C.c_void_p, [C.c_size_t]),
     "zkgpu_host_free": (None, [_P]),

@@ -54,6 +54,18 @@ class Context:
         self._h = h
         self.device = int(device)
 
+    def clone(self):
+        """zkgpu_ctx_clone: another context on the same GPU (own stream and buffers) that shares this one's SRS table
+        and prover key by reference; Prover.on(clone) gives the prover object for it."""
+        h = C.c_void_p()
+        self._check(self._lib.zkgpu_ctx_clone(self._h, C.byref(h)))
+        other = Context.__new__(Context)
+        other._lib, other._h, other.device = self._lib, h, self.device
+        return other
+
+    def device_bytes_shared(self):
+        return int(self._lib.zkgpu_device_bytes_shared(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.zkgpu_destroy(self._h)
@@ -438,6 +450,12 @@ class Prover:
         self.ctx, self.n = ctx, int(n.value)
         self.constraints = int.from_bytes(bytes(buf[40:48]), "big")
         return self
+
+    def on(self, ctx):
+        """This prover on a clone of its context (Context.clone): the same resident key, another stream."""
+        other = Prover.__new__(Prover)
+        other.ctx, other.n, other.constraints = ctx, self.n, self.constraints
+        return other
 
     def to_bytes(self):
         """Prover::to_bytes (plonk/src/compiler/prover.rs:85-134) as a numpy uint8 array."""

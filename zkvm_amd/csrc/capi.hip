@@ -172,6 +172,31 @@ void zkgpu_destroy(zkgpu_ctx *ctx) {
     delete ctx;
 }
 
+int zkgpu_ctx_clone(zkgpu_ctx *src, zkgpu_ctx **out) {
+    if (!src || !out) return ZKGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    zkgpu_ctx *ctx = nullptr;
+    int rc = zkgpu_init(&ctx, src->device);
+    if (rc != ZKGPU_OK) return rc;
+    rc = guarded(src, [&] {
+        ZK_HIP(hipStreamSynchronize(src->stream));   // whatever built the table and the key has finished
+        if (src->msm->n_points() > 0) ctx->msm->share_table(*src->msm);
+        ctx->prover->force_full_coset(src->prover->force_full());
+        if (src->prover->loaded()) ctx->prover->share_key(*src->prover);
+    });
+    if (rc != ZKGPU_OK) {
+        zkgpu_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return ZKGPU_OK;
+}
+
+size_t zkgpu_device_bytes_shared(const zkgpu_ctx *ctx) {
+    if (!ctx) return 0;
+    return ctx->msm->shared_table_bytes() + ctx->prover->shared_key_bytes();
+}
+
 const char *zkgpu_last_error(const zkgpu_ctx *ctx) {
     if (!ctx) return g_init_error.c_str();
     if (ctx == t_error_ctx) return t_error.c_str();

@@ -1024,13 +1024,14 @@ __device__ __forceinline__ void gstore_affine(G1Affine *p, const Fq &x, const Fq
 // Thread t extends point first + t: level w holds 2^(c w) * P in affine form.  The projective multiples are
 // written unnormalised first; their Z coordinates and running products go to scratch so that one inversion per
 // point converts all levels (Montgomery's trick along the levels).
-__global__ void __launch_bounds__(256) msm_table_kernel(G1Affine *table, G1Table28 *table28, uint32_t stride, uint32_t first,
-                                                        uint32_t count, uint32_t c, uint32_t K, Fq *z_scratch,
+// `upper` holds the unnormalised multiples of this chunk between the two halves: level w of thread t at (w - 1) * count + t.
+__global__ void __launch_bounds__(256) msm_table_kernel(const G1Affine *points, G1Affine *upper, G1Table28 *table28, uint32_t stride,
+                                                        uint32_t first, uint32_t count, uint32_t c, uint32_t K, Fq *z_scratch,
                                                         Fq *prefix_scratch) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const uint32_t i = first + t;
-    const G1Affine p = gload_affine(table + i);
+    const G1Affine p = gload_affine(points + i);
     gstore_affine28(table28 + i, affine_to_28(p));
     if (p.is_identity()) {
         G1Affine28 inf;
@@ -1046,7 +1047,7 @@ __global__ void __launch_bounds__(256) msm_table_kernel(G1Affine *table, G1Table
     Fq pre = Fq::one();
     for (uint32_t w = 1; w < K; w++) {
         for (uint32_t k = 0; k < c; k++) q = g1_double(q);
-        gstore_affine(table + (size_t)w * stride + i, q.x, q.y);
+        gstore_affine(upper + (size_t)(w - 1) * count + t, q.x, q.y);
         Fq z = q.z.is_zero() ? Fq::one() : q.z;   // cannot happen for points of prime order; keeps the product invertible
         pre = Fq::mul(pre, z);
         uint4 *zq = reinterpret_cast<uint4 *>(z_scratch + (size_t)(w - 1) * count + t);
@@ -1057,7 +1058,7 @@ __global__ void __launch_bounds__(256) msm_table_kernel(G1Affine *table, G1Table
     Fq inv = Fq::inv(pre);
     for (uint32_t w = K - 1; w >= 1; w--) {
         Fq z = gload_fq(reinterpret_cast<const uint4 *>(z_scratch + (size_t)(w - 1) * count + t));
-        G1Affine *slot = table + (size_t)w * stride + i;
+        const G1Affine *slot = upper + (size_t)(w - 1) * count + t;
         if (z.is_zero()) {
             G1Affine28 inf;
             inf.x = Fq28::zero();
@@ -1183,9 +1184,10 @@ struct MsmEngine::TailPool {
 
 MsmEngine::~MsmEngine() {
     delete tail_pool_;
-    DevBuf *all[] = {&points_, &counts_, &offsets_, &cursor_, &sorted_, &buckets_, &block_sums_, &tasks_, &partials_,
-                     &misc_,   &seg_,    &group_sums_, &order_, &digits_, &table28_, &range_cnt_, &mid_, &slice_tasks_};
+    DevBuf *all[] = {&counts_, &offsets_, &cursor_, &sorted_, &buckets_, &block_sums_, &tasks_, &partials_,
+                     &misc_,   &seg_,    &group_sums_, &order_, &digits_, &range_cnt_, &mid_, &slice_tasks_};
     for (DevBuf *b : all) b->release();
+    // points_ and table28_ are views of table_'s buffers, which go with the last engine that refers to them
     if (host_sums_) (void)hipHostFree(host_sums_);
 }
 
@@ -1250,31 +1252,52 @@ uint32_t MsmEngine::choose_window(size_t n) {
     return best;
 }
 
+void MsmEngine::new_table() {
+    n_points_ = 0;
+    points_ = DevBuf();
+    table28_ = DevBuf();
+    table_ = std::make_shared<PointTable>();   // the previous one goes with its last engine
+}
+
+void MsmEngine::share_table(const MsmEngine &src) {
+    table_ = src.table_;
+    points_ = src.points_;
+    table28_ = src.table28_;
+    n_points_ = src.n_points_;
+    c_ = src.c_;
+    K_ = src.K_;
+}
+
 void MsmEngine::build_table(size_t n) {
     c_ = window_override_ ? window_override_ : choose_window(n);
     K_ = 255 / c_ + 1;
     ZK_REQUIRE((uint64_t)n * K_ < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "srs_load: table of window multiples exceeds 2^31 entries");
     n_points_ = n;
     if (n == 0) return;
-    table28_.reserve((size_t)K_ * n * sizeof(G1Table28));
+    table_->table28.reserve((size_t)K_ * n * sizeof(G1Table28));
+    table28_ = table_->table28;
+    // per chunk of points: the Z coordinates and running products of the K - 1 upper levels (48 bytes each) and the
+    // unnormalised multiples themselves (96 bytes), all scratch of the build
     const uint32_t chunk = n < (1u << 18) ? (uint32_t)n : (1u << 18);
-    misc_.reserve((size_t)2 * (K_ - 1) * chunk * sizeof(Fq));
+    misc_.reserve((size_t)(K_ - 1) * chunk * (2 * sizeof(Fq) + sizeof(G1Affine)));
     Fq *z_scratch = misc_.as<Fq>(), *prefix_scratch = z_scratch + (size_t)(K_ - 1) * chunk;
+    G1Affine *upper = reinterpret_cast<G1Affine *>(prefix_scratch + (size_t)(K_ - 1) * chunk);
     for (size_t first = 0; first < n; first += chunk) {
         uint32_t count = (uint32_t)(n - first < chunk ? n - first : chunk);
-        hipLaunchKernelGGL(msm_table_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, stream_, points_.as<G1Affine>(),
+        hipLaunchKernelGGL(msm_table_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, stream_, points_.as<G1Affine>(), upper,
                            table28_.as<G1Table28>(), (uint32_t)n, (uint32_t)first, count, c_, K_, z_scratch, prefix_scratch);
     }
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(stream_));
+    misc_.release();   // up to 0.6 GiB of build scratch: nothing else uses it
 }
 
 void MsmEngine::load_points(const uint64_t *xy_host, const uint8_t *infinity_host, size_t n) {
     ZK_REQUIRE(xy_host != nullptr || n == 0, ZKGPU_ERR_INVALID_ARG, "srs_load: null points");
     ZK_REQUIRE(n < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "srs_load: more than 2^31 - 1 points");
-    n_points_ = 0;
-    const uint32_t c = window_override_ ? window_override_ : choose_window(n);
-    points_.reserve((size_t)(255 / c + 1) * n * sizeof(G1Affine) + 16);
+    new_table();
+    table_->points.reserve(n * sizeof(G1Affine) + 16);
+    points_ = table_->points;
     if (n) ZK_HIP(hipMemcpyAsync(points_.p, xy_host, n * sizeof(G1Affine), hipMemcpyHostToDevice, stream_));
     if (infinity_host && n) {
         bool any = false;
@@ -1293,9 +1316,9 @@ void MsmEngine::load_points(const uint64_t *xy_host, const uint8_t *infinity_hos
 
 void MsmEngine::setup_powers(const Fr &tau, const G1Affine &g, size_t n) {
     ZK_REQUIRE(n >= 1 && n < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "srs_setup: bad point count");
-    n_points_ = 0;
-    const uint32_t c = window_override_ ? window_override_ : choose_window(n);
-    points_.reserve((size_t)(255 / c + 1) * n * sizeof(G1Affine) + 16);
+    new_table();
+    table_->points.reserve(n * sizeof(G1Affine) + 16);
+    points_ = table_->points;
     hipLaunchKernelGGL(msm_powers_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, tau, g, (uint32_t)n,
                        points_.as<G1Affine>());
     ZK_HIP(hipGetLastError());
@@ -1356,9 +1379,9 @@ void MsmEngine::export_points_raw(uint8_t *out) {
 void MsmEngine::load_points_device(const void *xy_dev, size_t n) {
     ZK_REQUIRE(xy_dev != nullptr || n == 0, ZKGPU_ERR_INVALID_ARG, "srs_load: null points");
     ZK_REQUIRE(n < (1ull << 31), ZKGPU_ERR_INVALID_ARG, "srs_load: more than 2^31 - 1 points");
-    n_points_ = 0;
-    const uint32_t c = window_override_ ? window_override_ : choose_window(n);
-    points_.reserve((size_t)(255 / c + 1) * n * sizeof(G1Affine) + 16);
+    new_table();
+    table_->points.reserve(n * sizeof(G1Affine) + 16);
+    points_ = table_->points;
     if (n) ZK_HIP(hipMemcpyAsync(points_.p, xy_dev, n * sizeof(G1Affine), hipMemcpyDeviceToDevice, stream_));
     ZK_HIP(hipStreamSynchronize(stream_));
     build_table(n);

@@ -4,6 +4,7 @@
 #pragma once
 #include "common.hpp"
 #include "g1.hpp"
+#include <memory>
 #include <vector>
 
 namespace zk {
@@ -29,6 +30,13 @@ class MsmEngine {
     size_t raw_size() const { return 8 + 97 * n_points_; }
     void export_points_raw(uint8_t *out);
     size_t n_points() const { return n_points_; }
+    // Makes this engine use the point table `src` holds, by reference: the contexts cloned from one another on a GPU
+    // read one copy of the SRS and its window multiples (the reference's Prover is Clone and its clones share nothing
+    // mutable, plonk/src/compiler/prover.rs:20-30).  The table lives as long as any engine refers to it; a later load
+    // on either engine replaces only that engine's reference.  Both engines must be on the same device.
+    void share_table(const MsmEngine &src);
+    // bytes of the table when other engines refer to it too (they count in device_bytes() of every one of them)
+    size_t shared_table_bytes() const { return table_ && table_.use_count() > 1 ? points_.cap + table28_.cap : 0; }
 
     // sum_i scalars[i] * points[base + i], i < n.  `scalars_dev` holds n Fr elements in Montgomery form
     // (device memory).  Synchronous: returns the projective sum after the device work has finished.
@@ -75,7 +83,18 @@ class MsmEngine {
     hipStream_t stream_;
     void build_table(size_t n);
 
-    DevBuf points_;   // reference-form affine multiples, K levels (kept from the build)
+    // The resident points: owned by `table_`, which engines on one GPU may share; points_ and table28_ are this engine's
+    // views of its buffers (same pointers).
+    struct PointTable {
+        DevBuf points, table28;
+        ~PointTable() {
+            points.release();
+            table28.release();
+        }
+    };
+    std::shared_ptr<PointTable> table_;
+    void new_table();   // drops the reference to the current table and starts an empty one of this engine's own
+    DevBuf points_;   // the loaded points in the reference's affine form (what export_points returns)
     DevBuf table28_;  // table[w * n_points + i] = 2^(c w) * P_i, affine, unsaturated limbs (112 bytes), K levels
     size_t n_points_ = 0;
     uint32_t c_ = 0, K_ = 0, seg_bits_ = 0;

@@ -77,15 +77,105 @@ static void host_batch_inverse(std::vector<Fr> &v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-Prover::~Prover() {
-    polys_.release();
+Prover::KeyMem::~KeyMem() {
+    polys.release();
+    evals.release();
+    sigma.release();
+    pi_lagrange.release();
+    evals4.release();
+    sel_h.release();
+}
+
+void Prover::detach_key() {
+    if (!key_mem_) return;   // the views own their buffers (a load that failed half-way): reused or freed by the next one
+    if (evals_private_) evals_.release();
+    evals_private_ = false;
+    polys_ = evals_ = sigma_ = pi_lagrange_ = evals4_ = sel_h_ = DevBuf();
+    key_mem_.reset();
+}
+
+void Prover::publish_key() {
+    key_mem_ = std::make_shared<KeyMem>();
+    key_mem_->polys = polys_;
+    key_mem_->evals = evals_;
+    key_mem_->sigma = sigma_;
+    key_mem_->pi_lagrange = pi_lagrange_;
+    key_mem_->evals4 = evals4_;
+    key_mem_->sel_h = sel_h_;
+    evals_private_ = false;
+}
+
+void Prover::share_key(const Prover &src) {
+    ZK_REQUIRE(src.loaded(), ZKGPU_ERR_NOT_LOADED, "clone: the source context has no prover key");
+    ZK_REQUIRE(!src.shared() && src.key_mem_, ZKGPU_ERR_INVALID_ARG, "clone: a key loaded under set_collective is not shared");
+    detach_key();
+    polys_.release();   // what a failed load may have left in the views
     evals_.release();
     sigma_.release();
-    work_.release();
-    small_.release();
     pi_lagrange_.release();
     evals4_.release();
     sel_h_.release();
+    n_ = 0;
+    key_mem_ = src.key_mem_;
+    polys_ = src.polys_;
+    sigma_ = src.sigma_;
+    pi_lagrange_ = src.pi_lagrange_;
+    evals4_ = src.evals4_;
+    sel_h_ = src.sel_h_;
+    evals_private_ = false;
+    if (src.evals_private_) {   // built by src for itself after its load
+        evals_ = DevBuf();
+        evals8_built_ = false;
+    } else {
+        evals_ = src.evals_;
+        evals8_built_ = src.evals8_built_;
+    }
+    key_world_ = 1;
+    key_rank_ = 0;
+    ev_len_ = src.ev_len_;
+    log_n_ = src.log_n_;
+    constraints_ = src.constraints_;
+    vk_n_ = src.vk_n_;
+    label_ = src.label_;
+    seed_tr_.reset(src.seed_tr_ ? new MerlinTranscript(*src.seed_tr_) : nullptr);
+    pi_indexes_ = src.pi_indexes_;
+    for (int k = 0; k < N_SEL; k++) {
+        poly_len_[k] = src.poly_len_[k];
+        sel_comms_[k] = src.sel_comms_[k];
+    }
+    widgets_ = src.widgets_;
+    for (int k = 0; k < 8; k++) {
+        vh_[k] = src.vh_[k];
+        vh_inv_[k] = src.vh_inv_[k];
+    }
+    half_coset_ = src.half_coset_;
+    force_full_ = src.force_full_;
+    last_half_ = false;
+    proved_once_ = false;
+    for (int k = 0; k < 4; k++)
+        for (int j = 0; j < 7; j++) sigma_top_[k][j] = src.sigma_top_[k][j];
+    pi_lagrange_idx_ = src.pi_lagrange_idx_;
+    n_ = src.n_;
+}
+
+size_t Prover::shared_key_bytes() const {
+    if (!key_mem_ || key_mem_.use_count() < 2) return 0;
+    return polys_.cap + sigma_.cap + pi_lagrange_.cap + evals4_.cap + sel_h_.cap + (evals_private_ ? 0 : evals_.cap);
+}
+
+Prover::~Prover() {
+    if (key_mem_) {
+        detach_key();
+    } else {
+        polys_.release();
+        evals_.release();
+        sigma_.release();
+        pi_lagrange_.release();
+        evals4_.release();
+        sel_h_.release();
+    }
+    work_.release();
+    small_.release();
     tops_dev_.release();
     if (tops_host_) (void)hipHostFree(tops_host_);
     if (sums_ready_) (void)hipEventDestroy(sums_ready_);
@@ -307,6 +397,10 @@ void Prover::read_sigma_tops() {
 void Prover::ensure_evals8n() {
     if (evals8_built_) return;
     ZK_REQUIRE(loaded(), ZKGPU_ERR_NOT_LOADED, "no prover key loaded");
+    if (key_mem_) {   // a published key is read-only (other provers may refer to it): these vectors are this prover's own
+        evals_ = DevBuf();
+        evals_private_ = true;
+    }
     evals_.reserve((size_t)(N_SEL + 2) * ev_len_ * sizeof(Fr));
     small_.reserve(coset_buffer_bytes());
     build_key_evals(false, evals_.as<Fr>(), ev_len_, small_.as<Fr>(), true, true);
@@ -348,6 +442,7 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
     ZK_REQUIRE(msm_.n_points() > 0, ZKGPU_ERR_NOT_LOADED, "prover_key_load: load the SRS first");
     ZK_REQUIRE((uint64_t)n * 8 < (1ull << 32), ZKGPU_ERR_DOMAIN_SIZE, "InvalidEvalDomainSize: 8n must be below 2^32");
     n_ = 0;
+    detach_key();
     seed_tr_.reset();
     uint32_t log_n = 0;
     while ((1u << log_n) < n) log_n++;
@@ -412,6 +507,7 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
         }
     }
     build_pi_lagrange();
+    publish_key();
 }
 
 // ---- key (de)serialization --------------------------------------------------------------------------------------
@@ -559,6 +655,7 @@ void Prover::load_key_bytes(const uint8_t *b, size_t len, const uint64_t *pi_ind
 
     // CommitKey::from_slice_unchecked (kzg10/key.rs:54-66)
     n_ = 0;
+    detach_key();
     seed_tr_.reset();
     key_world_ = 1;
     key_rank_ = 0;
@@ -629,6 +726,7 @@ void Prover::load_key_bytes(const uint8_t *b, size_t len, const uint64_t *pi_ind
     }
     ZK_HIP(hipStreamSynchronize(stream_));
     build_pi_lagrange();
+    publish_key();
 }
 
 size_t Prover::to_bytes(uint8_t *out, size_t cap) {

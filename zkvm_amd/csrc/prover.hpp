@@ -81,6 +81,7 @@ class Prover {
     // on = true: keys loaded from now on prove over the full 8n coset whatever their gates (the reference's own route;
     // measurements and tests compare the two)
     void force_full_coset(bool on) { force_full_ = on; }
+    bool force_full() const { return force_full_; }
 
     // build_quotient_polynomial (quotient_poly.rs:15-100) on device polynomials; t_out must hold 8n elements.
     // Returns the coefficient count after truncating leading zeros.
@@ -112,6 +113,14 @@ class Prover {
     void prefetch_witness(const uint64_t *wires_host);
 
     size_t device_bytes() const;
+    // Makes this prover use the key `src` has loaded, by reference: coefficient vectors, coset vectors, sigma values and
+    // resident public-input vectors are read-only after the load, so the contexts of one GPU share one copy
+    // (#[derive(Clone)] Prover, plonk/src/compiler/prover.rs:20-21); everything a proof writes stays per prover.  Coset
+    // vectors that `src` built after its load (ensure_evals8n) are not shared: this prover builds its own when it needs
+    // them.  Not for keys loaded under set_collective.  Same device only.
+    void share_key(const Prover &src);
+    // bytes of the key vectors this prover refers to together with others
+    size_t shared_key_bytes() const;
 
    private:
     // CommitKey::commit (kzg10/key.rs:108-129) of a device polynomial
@@ -168,6 +177,16 @@ class Prover {
     uint32_t widgets_ = 0;
     Fr vh_[8], vh_inv_[8];   // the 8 distinct values of Z_H on the 8n coset and their inverses
     AffineOut sel_comms_[N_SEL];
+    // The key's device vectors are owned by key_mem_ once a load has succeeded (polys_ ... sel_h_ below are views of its
+    // buffers) and may be shared with other provers; evals_private_ marks 8n vectors this prover built for itself later.
+    struct KeyMem {
+        DevBuf polys, evals, sigma, pi_lagrange, evals4, sel_h;
+        ~KeyMem();
+    };
+    std::shared_ptr<KeyMem> key_mem_;
+    bool evals_private_ = false;
+    void detach_key();    // before a load: the views stop referring to a published key
+    void publish_key();   // after a load: the buffers the views own move into a fresh key_mem_
     DevBuf polys_;   // N_SEL x n coefficients
     DevBuf evals_;   // (N_SEL + 2) x 8n: selector coset evaluations, X on the coset, L1 on the coset
     DevBuf sigma_;   // 4 x n sigma values (their FFT is what compute_permutation_vec recomputes)

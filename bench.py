@@ -555,6 +555,9 @@ def run_prove(args, rank, world, local, device):
     if rank == 0 and not sharded and not args.no_sub_records:
         out["with_h2d"] = prove_with_transfers(prover, circ, blinders, n, proof, 1e3 * elapsed / args.steps, max(args.steps // 2, 4))
         out["proofs_in_flight"] = proofs_in_flight(prover, wires, circ, blinders, proof, max(args.steps // 2, 4), elapsed / args.steps)
+        if args.circuit == "widgets" or not args.no_widget_record:
+            out["widgets"] = widget_key_record(ctx, n, device, max(args.steps // 3, 3))
+            out["rooflines"].append(out["widgets"].pop("roofline"))
 
     # ---- the other parts of the metric, in the same run -----------------------------------------------------------
     if not args.no_sub_records and not sharded:
@@ -678,6 +681,53 @@ def prove_with_transfers(prover, circ, blinders, n, resident_proof, resident_ms,
             "pinned_prefetch_over_resident": round(overlap_ms / resident_ms, 4),
             "note": "pinned_prefetch: zkgpu_witness_prefetch uploads the next witness on a copy stream beside the current "
                     "proof (two device buffers); never the headline value, which has the witness resident in HBM"}
+
+
+def widget_key_record(ctx, n, device, steps):
+    """A key in which every widget has gates (range, logic, fixed-base scalar multiplication, curve addition:
+    zkvm_amd.circuits.widget_circuit), same row count: such a key proves over the reference's 8n coset, its quotient is
+    one launch per widget plus the launch of the arithmetic and permutation terms.  On a clone of the benchmark's
+    context (the SRS table is shared)."""
+    from zkvm_amd import api, circuits
+    wctx = ctx.clone()
+    try:
+        circ = circuits.widget_circuit(n)
+        circuits.fill_sigma_rows(circ, wctx)
+        t0 = time.perf_counter()
+        wp = api.Prover(wctx, n, circ["constraints"], circ["selectors"].reshape(-1, 4), b"bench-widgets", circ["pi_indexes"])
+        wctx.sync()
+        t_key = time.perf_counter() - t0
+        circ["selectors"] = None
+        w = to_dev(circ["wires"].reshape(-1, 4), device)
+        bl = circuits.random_blinders(2)
+        first = wp.prove(w, circ["public_inputs"], bl)
+        wctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = wp.prove(w, circ["public_inputs"], bl)
+        wctx.sync()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        assert last["coset"] == 8 and np.array_equal(first["comms"], last["comms"])
+        q_ms = wctx.quotient_kernel_ms()
+        points = 8.0 * n
+        # widget products per point as the formulas are written (widgets.hpp): range 20, logic 37, fixed-base 26, curve
+        # addition 15, two more each for selector and challenge; arithmetic and permutation 25
+        products = 20 + 37 + 26 + 15 + 4 * 2 + 25
+        streams = 19 + 4 + 3 + 2       # the arithmetic kernel's, four widget selectors, three "next row" reads, the sum twice
+        alg = points * 32 * (streams + 1)
+        mad_rate = points * products * FR_MADS / 64 / (q_ms * 1e-3) / 1e9
+        roof = {"bound": "valu", "kernel": "quotient of a key with every widget: quotient_widget_kernel<0..3> + quotient_limb_kernel "
+                                           "(8n = %d points, 5 launches)" % int(points),
+                "avg_launch_ms": round(q_ms / 5, 4), "phase_ms": round(q_ms, 4),
+                "achieved": round(mad_rate, 1), "peak": MAD_PEAK_G, "unit": "G v_mad_u64_u32 wave-instructions/s",
+                "frac": round(mad_rate / MAD_PEAK_G, 3), "field_products_per_point": products,
+                "hbm": {"algorithmic_bytes": int(alg), "achieved": round(alg / (q_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(alg / (q_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+        return {"circuit": "every widget in use (zkvm_amd.circuits.widget_circuit), 2^%d rows" % (n.bit_length() - 1),
+                "ms_per_proof": round(ms, 3), "quotient_coset": "8n points (the reference's coset)",
+                "quotient_kernels_ms": round(q_ms, 4), "key_preprocess_s": round(t_key, 3), "steps": steps, "roofline": roof}
+    finally:
+        wctx.close()
 
 
 def proofs_in_flight(prover, wires, circ, blinders, resident_proof, steps, one_at_a_time_s):
@@ -823,6 +873,9 @@ def main():
                     help="time the CPU oracle on the full 2^log-gates proof (minutes) instead of the bounded sample")
     ap.add_argument("--no-sub-records", action="store_true",
                     help="prove workload: leave out the msm / ntt / msm_scaling / sharded_prove records")
+    ap.add_argument("--circuit", default="arithmetic", choices=["arithmetic", "widgets"],
+                    help="prove workload: `widgets` keeps the sub-record of a key with every widget even under --no-widget-record")
+    ap.add_argument("--no-widget-record", action="store_true", help="prove workload: leave out the widget-key record")
     ap.add_argument("--full-coset", action="store_true",
                     help="prove workload: evaluate the quotient over the reference's 8n coset even where 4n points suffice")
     ap.add_argument("--msm-window", type=int, default=0, help="tuning: force the MSM window width (0 = the engine's choice)")

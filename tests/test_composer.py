@@ -243,3 +243,45 @@ def test_gpu_proof_with_curve_widgets(orc):
             assert np.array_equal(got[key], want[key]), key
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("subset", [(0, 1, 2, 3), (0,), (1,), (2,), (3,), (1, 3)])
+def test_gpu_proof_with_every_widget_in_one_key(orc, subset):
+    """circuits.widget_circuit: range, logic, fixed-base and curve-addition gates in one key of 2^12 rows (one launch per
+    widget whose selector is not identically zero, summed per point, then the arithmetic and permutation terms); for
+    the subsets the other widgets' selector rows are zeroed, which leaves their gates unconstrained but satisfied.
+    Proof = the oracle's, accepted by the verifier, and a violated range gate ends in the oracle's error."""
+    import plonk_check
+    import zkvm_amd
+    from zkvm_amd import api, circuits
+    circ = circuits.widget_circuit(1 << 12, repeats=2)
+    for w in range(4):
+        if w not in subset:
+            circ["selectors"][7 + w] = 0
+    op, srs, tau = _oracle_prover(orc, circ, b"all-widgets")
+    ctx = zkvm_amd.Context(0)
+    try:
+        ctx.srs_load(srs)
+        gp = api.Prover(ctx, circ["n"], circ["constraints"], circ["selectors"].reshape(-1, 4), b"all-widgets", circ["pi_indexes"])
+        bl = circuits.random_blinders(11)
+        want = op.prove(circ["wires"], circ["public_inputs"], bl)
+        got = gp.prove(circ["wires"].reshape(-1, 4), circ["public_inputs"], bl)
+        assert want["rc"] == 0 and got["coset"] == 8
+        for key in ("challenges", "evals", "comms_inf", "comms"):
+            assert np.array_equal(got[key], want[key]), key
+        if subset == (0, 1, 2, 3):
+            sxy, sinf = gp.selector_commitments()
+            gxy, _ = orc.g1_to_affine(orc.g1_generator())
+            h, tau_h = plonk_check.opening_key_g2(tau)
+            assert plonk_check.verify(circ["n"], circ["constraints"], b"all-widgets", got, sxy, sinf, circ["public_inputs"],
+                                      circ["pi_indexes"], gxy, h, tau_h, orc)
+        if 0 in subset:
+            row = int(np.nonzero(circ["selectors"][7].any(axis=1))[0][3])
+            bad = circ["wires"].copy()
+            bad[1, row, 0] ^= np.uint64(4)
+            assert op.prove(bad, circ["public_inputs"], bl)["rc"] == 2
+            with pytest.raises(api.PolynomialDegreeTooLarge):
+                gp.prove(bad.reshape(-1, 4), circ["public_inputs"], bl)
+    finally:
+        ctx.close()

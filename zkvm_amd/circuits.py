@@ -118,6 +118,40 @@ def arithmetic_circuit(n, constraints=None, seed=5, copy_fraction=0.5):
                 public_inputs=ints_to_limbs([pi0]), pi_indexes=[0])
 
 
+def widget_circuit(n, repeats=8):
+    """A circuit of n rows in which every widget has gates: `repeats` times a 32-bit range check, a 32-bit AND and XOR,
+    a fixed-base scalar multiplication and a curve addition (built gate by gate by zkvm_amd.composer), then all-zero
+    rows up to n - 6 constraints (a row whose selectors and wires are zero is satisfied).  Same layout as
+    arithmetic_circuit, sigma rows still empty."""
+    from . import composer as C
+    c = C.Composer.initialized()
+    for r in range(repeats):
+        a = c.append_witness(0xbeefcafe + 977 * r)
+        b = c.append_witness(0x0f0f3333 + 31 * r)
+        c.component_range(a, 16)
+        w_and = c.append_logic_and(a, b, 16)
+        w_xor = c.append_logic_xor(a, b, 16)
+        if r == 0:
+            c.assert_equal(w_and, c.append_public(c[w_and]))
+            c.assert_equal(w_xor, c.append_public(c[w_xor]))
+        k = c.append_witness(0x1234567890abcdef1234567 + r)
+        p = c.component_mul_generator(k)
+        g = c.append_point(C.JUBJUB_GENERATOR)
+        c.component_add_point(g, p)
+    t = c.tables()
+    m = t["n"]
+    assert n >= 2 * m, "the widget gates need %d rows" % m
+    sel = np.zeros((15, n, 4), dtype=np.uint64)
+    sel[:, :m] = t["selectors"]
+    wires = np.zeros((4, n, 4), dtype=np.uint64)
+    wires[:, :m] = t["wires"]
+    sigma = np.arange(4 * n, dtype=np.uint64).reshape(4, n)
+    col, row = np.divmod(t["sigma_map"], np.uint64(m))          # entries are column * m + gate
+    sigma[:, :m] = col * np.uint64(n) + row
+    return dict(n=n, constraints=n - 6 if n > 8 else n, selectors=sel, sigma_map=sigma, wires=wires,
+                public_inputs=t["public_inputs"], pi_indexes=t["pi_indexes"])
+
+
 def fill_sigma_rows(circuit, ctx):
     """Writes the four sigma rows: sigma value = K[col'] * w^(idx') for sigma(col, i) = (col', idx')
     (composer/permutation.rs:111-141).  The roots come from the GPU: fft(K * e_1)[i] = K * w^i."""

@@ -272,67 +272,42 @@ struct OutlinedMul {
 };
 #define FM(a, b) fr_mul_outlined((a), (b))
 
-// WIDGETS = false compiles the arithmetic and permutation terms only (circuits whose range, logic and curve
-// selectors are identically zero): with every widget compiled in, the kernel needs all 256 VGPRs and runs one wave
-// per SIMD, which leaves nothing to hide the latency of its two dozen streams.
-template <bool WIDGETS>
-__global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs q) {
+// The range, logic, fixed-base and curve-addition terms (widget `compute_quotient_i`, each multiplied by its selector
+// and its separation challenge) are evaluated by a launch of their own per widget whose selector polynomial is not
+// identically zero, and summed per point in `sum`; quotient_limb_kernel adds that sum to the arithmetic and permutation
+// terms.  Field addition is exact, so the order of the terms does not show in the result.  One kernel with every widget
+// compiled in needs all 256 VGPRs and runs one wave per SIMD, which leaves nothing to hide the latency of its two dozen
+// streams; a widget alone needs under half of that.
+//   W = 0 range/proverkey.rs:31-59, 1 logic/proverkey.rs:34-78, 2 ecc/scalar_mul/fixed_base/proverkey.rs:38-101,
+//   3 ecc/curve_addition/proverkey.rs:32-83
+template <int W>
+__global__ void __launch_bounds__(256) quotient_widget_kernel(QuotientArgs q, Fr *sum, bool first) {
     typedef OutlinedMul M;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= q.n8) return;
     const uint32_t iw = (i + q.rot) & (q.n8 - 1);  // "next row" on the 8n coset (quotient_poly.rs:53-59,134-136)
     const Fr a = ld(q.a + i), b = ld(q.b + i), c = ld(q.c + i), d = ld(q.d + i);
-
-    // arithmetic/proverkey.rs:43-73
-    Fr t = FM(FM(a, b), ld(q.sel[Q_M] + i));
-    t = Fr::add(t, FM(a, ld(q.sel[Q_L] + i)));
-    t = Fr::add(t, FM(b, ld(q.sel[Q_R] + i)));
-    t = Fr::add(t, FM(c, ld(q.sel[Q_O] + i)));
-    t = Fr::add(t, FM(d, ld(q.sel[Q_F] + i)));
-    t = Fr::add(t, ld(q.sel[Q_C] + i));
-    t = FM(t, ld(q.sel[Q_ARITH] + i));
-
-    if (WIDGETS && q.widgets) {  // every other widget is multiplied by its selector: zero selectors contribute exactly 0
-        const Fr a_w = ld(q.a + iw), b_w = ld(q.b + iw), d_w = ld(q.d + iw);
-        if (q.widgets & 1u) {  // range/proverkey.rs:31-59
-            Fr s = w_range_identity<M>(q.range_ch, a, b, c, d, d_w);
-            t = Fr::add(t, FM(FM(s, ld(q.sel[Q_RANGE] + i)), q.range_ch));
-        }
-        if (q.widgets & 2u) {  // logic/proverkey.rs:34-78
-            Fr s = w_logic_identity<M>(q.logic_ch, a, a_w, b, b_w, c, d, d_w, ld(q.sel[Q_C] + i));
-            t = Fr::add(t, FM(FM(ld(q.sel[Q_LOGIC] + i), s), q.logic_ch));
-        }
-        if (q.widgets & 4u) {  // ecc/scalar_mul/fixed_base/proverkey.rs:38-101
-            Fr s = w_fixed_base_identity<M>(q.fixed_ch, a, a_w, b, b_w, c, d, d_w, ld(q.sel[Q_L] + i), ld(q.sel[Q_R] + i),
-                                            ld(q.sel[Q_C] + i));
-            t = Fr::add(t, FM(FM(s, ld(q.sel[Q_FIXED] + i)), q.fixed_ch));
-        }
-        if (q.widgets & 8u) {  // ecc/curve_addition/proverkey.rs:32-83
-            Fr s = w_curve_add_identity<M>(q.var_ch, a, a_w, b, b_w, c, d, d_w);
-            t = Fr::add(t, FM(FM(s, ld(q.sel[Q_VAR] + i)), q.var_ch));
+    const Fr d_w = ld(q.d + iw);
+    Fr t;
+    if (W == 0) {
+        const Fr s = w_range_identity<M>(q.sep_k[0], a, b, c, d, d_w);
+        t = FM(FM(s, ld(q.sel[Q_RANGE] + i)), q.range_ch);
+    } else {
+        const Fr a_w = ld(q.a + iw), b_w = ld(q.b + iw);
+        if (W == 1) {
+            const Fr s = w_logic_identity<M>(q.sep_k[1], a, a_w, b, b_w, c, d, d_w, ld(q.sel[Q_C] + i));
+            t = FM(FM(ld(q.sel[Q_LOGIC] + i), s), q.logic_ch);
+        } else if (W == 2) {
+            const Fr s = w_fixed_base_identity<M>(q.sep_k[2], a, a_w, b, b_w, c, d, d_w, ld(q.sel[Q_L] + i), ld(q.sel[Q_R] + i),
+                                                  ld(q.sel[Q_C] + i));
+            t = FM(FM(s, ld(q.sel[Q_FIXED] + i)), q.fixed_ch);
+        } else {
+            const Fr s = w_curve_add_identity<M>(q.sep_k[3], a, a_w, b, b_w, c, d, d_w);
+            t = FM(FM(s, ld(q.sel[Q_VAR] + i)), q.var_ch);
         }
     }
-    t = Fr::add(t, ld(q.pi + i));
-
-    // permutation/proverkey.rs:39-119
-    const Fr z = ld(q.z + i), z_w = ld(q.z + iw);
-    const Fr bx = FM(q.beta, ld(q.linear + i));
-    Fr id = Fr::add(Fr::add(a, bx), q.gamma);
-    id = FM(id, Fr::add(Fr::add(b, mul_small<7>(bx)), q.gamma));
-    id = FM(id, Fr::add(Fr::add(c, mul_small<13>(bx)), q.gamma));
-    id = FM(id, Fr::add(Fr::add(d, mul_small<17>(bx)), q.gamma));
-    id = FM(id, z);
-    Fr cp = Fr::add(Fr::add(a, FM(q.beta, ld(q.sel[S1] + i))), q.gamma);
-    cp = FM(cp, Fr::add(Fr::add(b, FM(q.beta, ld(q.sel[S2] + i))), q.gamma));
-    cp = FM(cp, Fr::add(Fr::add(c, FM(q.beta, ld(q.sel[S3] + i))), q.gamma));
-    cp = FM(cp, Fr::add(Fr::add(d, FM(q.beta, ld(q.sel[S4] + i))), q.gamma));
-    cp = FM(cp, z_w);
-    Fr p = FM(Fr::sub(id, cp), q.alpha);  // id * alpha - cp * alpha
-    // (z - 1) * L1 * alpha^2 ; q.l1 holds L1 on the coset, q.alpha_sq = alpha^2
-    p = Fr::add(p, FM(FM(Fr::sub(z, Fr::one()), ld(q.l1 + i)), q.alpha_sq));
-
-    // quotient_poly.rs:88-95: numerator / Z_H ; Z_H takes 8 values on the 8n coset
-    st(q.out + i, FM(Fr::add(t, p), q.vh_inv[(q.first + q.world * i) & 7]));
+    if (!first) t = Fr::add(t, ld(sum + i));
+    st(sum + i, t);
 }
 
 // ---- the same identity on unsaturated limbs, for circuits with the arithmetic and permutation terms only ---------
@@ -421,10 +396,11 @@ __global__ void __launch_bounds__(256) quotient_limb_kernel(QuotientArgs q) {
 #pragma unroll
     for (int k = 0; k < 9; k++) zm.v[k] += bias[k] - one.v[k];      // z - 1 + 4r: below 5
     u9_add(t.v, LM(LM(zm, l9x32(ld(q.l1 + i))), l9x32(q.alpha_sq)).v);     // 3.1 -> + below 2.3: t below 11.4
+    if (q.widget_sum) u9_add(t.v, l9(ld(q.widget_sum + i)).v);             // canonical: t below 12.4
     u9_normalize(t.v);
 
     // quotient_poly.rs:88-95: numerator / Z_H
-    t = LM(t, l9x32(q.vh_inv[(q.first + q.world * i) & 7]));        // below 5.8
+    t = LM(t, l9x32(q.vh_inv[(q.first + q.world * i) & 7]));        // below 6.2
     u9_qreduce(t.v);
     Fr::cond_sub_limbs(t.v);
     st(q.out + i, Fr::pack(t.v));
@@ -438,15 +414,41 @@ void PolyEngine::quotient(const QuotientArgs &args) {
         ZK_HIP(hipEventCreate(&q_ev_[0]));
         ZK_HIP(hipEventCreate(&q_ev_[1]));
     }
+    QuotientArgs q = args;
+    q.beta_x32 = mul_small<32>(args.beta);
+    q.gamma_x32 = mul_small<32>(args.gamma);
+    q.widget_sum = nullptr;
+    if (args.widgets) {
+        q.sep_k[0] = sep_powers<InlineMul>(args.range_ch);
+        q.sep_k[1] = sep_powers<InlineMul>(args.logic_ch);
+        q.sep_k[2] = sep_powers<InlineMul>(args.fixed_ch);
+        q.sep_k[3] = sep_powers<InlineMul>(args.var_ch);
+    }
+    if (args.widgets) widget_sum_.reserve((size_t)args.n8 * sizeof(Fr));   // before the timed region: may allocate
     ZK_HIP(hipEventRecord(q_ev_[0], stream_));
     if (args.widgets) {
-        hipLaunchKernelGGL(quotient_kernel<true>, dim3(ceil_div(args.n8, 256)), dim3(256), 0, stream_, args);
-    } else {
-        QuotientArgs q = args;
-        q.beta_x32 = mul_small<32>(args.beta);
-        q.gamma_x32 = mul_small<32>(args.gamma);
-        hipLaunchKernelGGL(quotient_limb_kernel, dim3(ceil_div(args.n8, 256)), dim3(256), 0, stream_, q);
+        Fr *sum = widget_sum_.as<Fr>();
+        const dim3 grid(ceil_div(args.n8, 256)), block(256);
+        bool first = true;
+        if (args.widgets & 1u) {
+            hipLaunchKernelGGL(quotient_widget_kernel<0>, grid, block, 0, stream_, q, sum, first);
+            first = false;
+        }
+        if (args.widgets & 2u) {
+            hipLaunchKernelGGL(quotient_widget_kernel<1>, grid, block, 0, stream_, q, sum, first);
+            first = false;
+        }
+        if (args.widgets & 4u) {
+            hipLaunchKernelGGL(quotient_widget_kernel<2>, grid, block, 0, stream_, q, sum, first);
+            first = false;
+        }
+        if (args.widgets & 8u) {
+            hipLaunchKernelGGL(quotient_widget_kernel<3>, grid, block, 0, stream_, q, sum, first);
+            first = false;
+        }
+        q.widget_sum = sum;
     }
+    hipLaunchKernelGGL(quotient_limb_kernel, dim3(ceil_div(args.n8, 256)), dim3(256), 0, stream_, q);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipEventRecord(q_ev_[1], stream_));
     q_recorded_ = true;
@@ -878,6 +880,7 @@ PolyEngine::~PolyEngine() {
     s2_.release();
     s3_.release();
     jobs_.release();
+    widget_sum_.release();
 }
 
 }  // namespace zk

@@ -3,6 +3,7 @@
 // division.  All pointers are device pointers; everything is asynchronous on the engine's stream.
 #pragma once
 #include "common.hpp"
+#include "widgets.hpp"
 #include "ff.hpp"
 
 namespace zk {
@@ -25,6 +26,8 @@ struct QuotientArgs {
     // (first + world * k) mod 8.  One GPU: rot = 8, world = 1, first = 0.
     uint32_t rot, world, first;
     uint32_t widgets;                  // bit 0 range, 1 logic, 2 fixed-base, 3 curve-addition: selector is non-zero
+    SepPowers sep_k[4];                // powers of the four separation challenges squared (filled in by PolyEngine::quotient)
+    const Fr *widget_sum;              // sum of the active widgets' terms per point (filled in by PolyEngine::quotient), or null
 };
 
 struct EvalJob {
@@ -104,11 +107,12 @@ class PolyEngine {
     // has run past this call
     void lengths_enqueue(uint32_t m, const Fr *const *coeffs, const uint64_t *lens, unsigned long long *host_out);
 
-    size_t device_bytes() const { return s0_.cap + s1_.cap + s2_.cap + s3_.cap + jobs_.cap; }
+    size_t device_bytes() const { return s0_.cap + s1_.cap + s2_.cap + s3_.cap + jobs_.cap + widget_sum_.cap; }
 
    private:
     hipStream_t stream_;
     DevBuf s0_, s1_, s2_, s3_, jobs_;
+    DevBuf widget_sum_;   // per coset point: the range / logic / curve terms of a key that has such gates
     hipEvent_t q_ev_[2] = {nullptr, nullptr};   // around the quotient kernel, created at the first launch
     bool q_recorded_ = false;
 };

@@ -1092,13 +1092,13 @@ uint64_t Prover::linearization(const Fr ch7[7], const Fr &z_ch, const Fr *e, con
     term(key_poly(Q_F), n, Fr::mul(e[D], qa));
     term(key_poly(Q_C), n, qa);
     // range / logic / fixed-base / curve-addition compute_linearization
-    term(key_poly(Q_RANGE), n, Fr::mul(w_range_identity<M>(range_ch, e[A], e[B], e[C], e[D], e[DW]), range_ch));
+    term(key_poly(Q_RANGE), n, Fr::mul(w_range_identity<M>(sep_powers<M>(range_ch), e[A], e[B], e[C], e[D], e[DW]), range_ch));
     term(key_poly(Q_LOGIC), n,
-         Fr::mul(w_logic_identity<M>(logic_ch, e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW], e[QC]), logic_ch));
+         Fr::mul(w_logic_identity<M>(sep_powers<M>(logic_ch), e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW], e[QC]), logic_ch));
     term(key_poly(Q_FIXED), n,
-         Fr::mul(w_fixed_base_identity<M>(fixed_ch, e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW], e[QL], e[QR], e[QC]),
+         Fr::mul(w_fixed_base_identity<M>(sep_powers<M>(fixed_ch), e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW], e[QL], e[QR], e[QC]),
                  fixed_ch));
-    term(key_poly(Q_VAR), n, Fr::mul(w_curve_add_identity<M>(var_ch, e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW]), var_ch));
+    term(key_poly(Q_VAR), n, Fr::mul(w_curve_add_identity<M>(sep_powers<M>(var_ch), e[A], e[AW], e[B], e[BW], e[C], e[D], e[DW]), var_ch));
     // permutation/proverkey.rs:121-245
     const Fr beta_z = Fr::mul(beta, z_ch);
     Fr acc = Fr::add(Fr::add(e[A], beta_z), gamma);

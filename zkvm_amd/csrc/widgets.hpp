@@ -27,14 +27,29 @@ FF_HD Fr mul_small(const Fr &a) {
     }
 }
 
-// coset-jubjub/src/lib.rs:368-373 (EDWARDS_D), converted into Montgomery form with one product
+// coset-jubjub/src/lib.rs:368-373 (EDWARDS_D = -10240 / 10241), in Montgomery form
 template <class M>
 FF_HD Fr edwards_d() {
-    Fr raw;
-    const uint32_t w[8] = {0xd6343eb1u, 0x01065fd6u, 0x37579d26u, 0x292d7f6du, 0xe6bd7fd4u, 0xf5fd9207u, 0x4bfa2b48u, 0x2a9318e7u};
+    Fr d;
+    const uint32_t w[8] = {0xb974f6b0u, 0x2a522455u, 0x0d9acab3u, 0xfc6cc9efu, 0xc27628d1u, 0x7a08fb94u, 0xfe0e262eu, 0x57f8f6a8u};
 #pragma unroll
-    for (int i = 0; i < 8; i++) raw.v[i] = w[i];
-    return M::mul(raw, Fr::r2());
+    for (int i = 0; i < 8; i++) d.v[i] = w[i];
+    return d;
+}
+
+// Powers of kappa = separation_challenge^2, the weights of a widget's sub-identities: the same for every point of a
+// proof, so the quotient kernels receive them ready-made.
+struct SepPowers {
+    Fr k1, k2, k3, k4;
+};
+template <class M>
+FF_HD SepPowers sep_powers(const Fr &sep) {
+    SepPowers k;
+    k.k1 = M::mul(sep, sep);
+    k.k2 = M::mul(k.k1, k.k1);
+    k.k3 = M::mul(k.k2, k.k1);
+    k.k4 = M::mul(k.k3, k.k1);
+    return k;
 }
 
 // range/proverkey.rs:92-97 and logic/proverkey.rs:124-129: f (f-1) (f-2) (f-3)
@@ -47,8 +62,8 @@ FF_HD Fr w_delta(const Fr &f) {
 
 // range/proverkey.rs:44-56 (quotient) and :69-84 (linearization): the sum before "* q_range * separator"
 template <class M>
-FF_HD Fr w_range_identity(const Fr &sep, const Fr &a, const Fr &b, const Fr &c, const Fr &d, const Fr &d_w) {
-    Fr kappa = M::mul(sep, sep), kappa_sq = M::mul(kappa, kappa), kappa_cu = M::mul(kappa_sq, kappa);
+FF_HD Fr w_range_identity(const SepPowers &k, const Fr &a, const Fr &b, const Fr &c, const Fr &d, const Fr &d_w) {
+    const Fr &kappa = k.k1, &kappa_sq = k.k2, &kappa_cu = k.k3;
     Fr s = w_delta<M>(Fr::sub(c, mul_small<4>(d)));
     s = Fr::add(s, M::mul(w_delta<M>(Fr::sub(b, mul_small<4>(c))), kappa));
     s = Fr::add(s, M::mul(w_delta<M>(Fr::sub(a, mul_small<4>(b))), kappa_sq));
@@ -71,10 +86,9 @@ FF_HD Fr w_delta_xor_and(const Fr &a, const Fr &b, const Fr &w, const Fr &c, con
 
 // logic/proverkey.rs:51-77 and :88-118: c_0 + ... + c_4
 template <class M>
-FF_HD Fr w_logic_identity(const Fr &sep, const Fr &a, const Fr &a_w, const Fr &b, const Fr &b_w, const Fr &c, const Fr &d,
+FF_HD Fr w_logic_identity(const SepPowers &k, const Fr &a, const Fr &a_w, const Fr &b, const Fr &b_w, const Fr &c, const Fr &d,
                           const Fr &d_w, const Fr &q_c) {
-    Fr kappa = M::mul(sep, sep), kappa_sq = M::mul(kappa, kappa), kappa_cu = M::mul(kappa_sq, kappa),
-       kappa_qu = M::mul(kappa_cu, kappa);
+    const Fr &kappa = k.k1, &kappa_sq = k.k2, &kappa_cu = k.k3, &kappa_qu = k.k4;
     Fr ai = Fr::sub(a_w, mul_small<4>(a)), bi = Fr::sub(b_w, mul_small<4>(b)), di = Fr::sub(d_w, mul_small<4>(d));
     Fr c0 = w_delta<M>(ai);
     Fr c1 = M::mul(w_delta<M>(bi), kappa);
@@ -86,10 +100,10 @@ FF_HD Fr w_logic_identity(const Fr &sep, const Fr &a, const Fr &a_w, const Fr &b
 
 // ecc/scalar_mul/fixed_base/proverkey.rs:53-98 and :110-154
 template <class M>
-FF_HD Fr w_fixed_base_identity(const Fr &sep, const Fr &a, const Fr &a_w, const Fr &b, const Fr &b_w, const Fr &c,
+FF_HD Fr w_fixed_base_identity(const SepPowers &k, const Fr &a, const Fr &a_w, const Fr &b, const Fr &b_w, const Fr &c,
                                const Fr &d, const Fr &d_w, const Fr &q_l, const Fr &q_r, const Fr &q_c) {
     const Fr one = Fr::one();
-    Fr kappa = M::mul(sep, sep), kappa_sq = M::mul(kappa, kappa), kappa_cu = M::mul(kappa_sq, kappa);
+    const Fr &kappa = k.k1, &kappa_sq = k.k2, &kappa_cu = k.k3;
     Fr bit = Fr::sub(Fr::sub(d_w, d), d);                                            // extract_bit :160-162
     Fr bit_cons = M::mul(M::mul(bit, Fr::sub(bit, one)), Fr::add(bit, one));          // :164-167
     Fr y_alpha = Fr::add(M::mul(M::mul(bit, bit), Fr::sub(q_r, one)), one);
@@ -107,14 +121,14 @@ FF_HD Fr w_fixed_base_identity(const Fr &sep, const Fr &a, const Fr &a_w, const 
 
 // ecc/curve_addition/proverkey.rs:46-80 and :92-124 ; x1 = a, x3 = a_w, y1 = b, y3 = b_w, x2 = c, y2 = d, x1*y2 = d_w
 template <class M>
-FF_HD Fr w_curve_add_identity(const Fr &sep, const Fr &a, const Fr &a_w, const Fr &b, const Fr &b_w, const Fr &c,
+FF_HD Fr w_curve_add_identity(const SepPowers &k, const Fr &a, const Fr &a_w, const Fr &b, const Fr &b_w, const Fr &c,
                               const Fr &d, const Fr &d_w) {
-    Fr kappa = M::mul(sep, sep);
+    const Fr &kappa = k.k1;
     Fr xy_cons = Fr::sub(M::mul(a, d), d_w);
     Fr y1x2 = M::mul(b, c), y1y2 = M::mul(b, d), x1x2 = M::mul(a, c);
     Fr dd = M::mul(M::mul(edwards_d<M>(), d_w), y1x2);
     Fr x3c = M::mul(Fr::sub(Fr::add(d_w, y1x2), Fr::add(a_w, M::mul(a_w, dd))), kappa);
-    Fr y3c = M::mul(Fr::sub(Fr::add(y1y2, x1x2), Fr::sub(b_w, M::mul(b_w, dd))), M::mul(kappa, kappa));
+    Fr y3c = M::mul(Fr::sub(Fr::add(y1y2, x1x2), Fr::sub(b_w, M::mul(b_w, dd))), k.k2);
     return Fr::add(Fr::add(xy_cons, x3c), y3c);
 }
 

@@ -922,6 +922,10 @@ def main():
                      "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "vs_baseline": None,
                      "data": "synthetic (seeded circuits and scalars; SRS = powers of a seeded tau times the G1 generator)"})
         line.update(extra)
+        from zkvm_amd import _lib
+        line["library"] = os.path.relpath(_lib.LIB_PATH, ROOT)
+        if _lib.LIB_OVERRIDDEN:
+            line["library_note"] = "ZKGPU_LIB override: an A/B measurement, not this tree's library"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = (cpu_baseline_prove(args.log_gates, args.cpu_baseline_full) if args.workload == "prove" else
                                     cpu_baseline_ntt() if args.workload == "ntt" else cpu_baseline_msm())

@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The suite checks THIS tree's libzkgpu.so: a stale ZKGPU_LIB (the A/B switch of zkvm_amd/_lib.py) would silently put
+    # another build under test.
+    if os.environ.get("ZKGPU_LIB") and os.environ.get("ZKGPU_ALLOW_LIB_OVERRIDE") != "1":
+        raise pytest.UsageError("ZKGPU_LIB is set: unset it, or set ZKGPU_ALLOW_LIB_OVERRIDE=1 to test that library on purpose")
 
 
 @pytest.fixture(scope="session")

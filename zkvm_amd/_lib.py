@@ -8,8 +8,12 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ZKGPU_LIB names another build of the library (A/B measurements of kernel variants)
-LIB_PATH = os.environ.get("ZKGPU_LIB") or os.path.join(_HERE, "libzkgpu.so")
+# ZKGPU_LIB names another build of the library, for A/B measurements of kernel variants only: the override is announced
+# on stderr when the library is loaded, bench.py records the path it measured, and the test suite and the smoke entry
+# refuse to run under it.
+DEFAULT_LIB_PATH = os.path.join(_HERE, "libzkgpu.so")
+LIB_PATH = os.environ.get("ZKGPU_LIB") or DEFAULT_LIB_PATH
+LIB_OVERRIDDEN = os.path.abspath(LIB_PATH) != os.path.abspath(DEFAULT_LIB_PATH)
 
 ERRORS = {
     -1: "ZKGPU_ERR_INVALID_ARG", -2: "ZKGPU_ERR_HIP", -3: "ZKGPU_ERR_NO_DEVICE", -4: "ZKGPU_ERR_DOMAIN_SIZE",
@@ -127,8 +131,16 @@ def lib():
         except ImportError:
             pass
         l = C.CDLL(LIB_PATH)
+        if LIB_OVERRIDDEN:
+            import sys
+            print("zkvm_amd: ZKGPU_LIB is set, using %s instead of %s" % (LIB_PATH, DEFAULT_LIB_PATH), file=sys.stderr, flush=True)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                if not LIB_OVERRIDDEN:
+                    raise
+                continue   # an older build under comparison lacks the newer entry points
             fn.restype = res
             fn.argtypes = args
         _lib = l

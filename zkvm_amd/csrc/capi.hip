@@ -194,6 +194,7 @@ int zkgpu_ctx_clone(zkgpu_ctx *src, zkgpu_ctx **out) {
 
 size_t zkgpu_device_bytes_shared(const zkgpu_ctx *ctx) {
     if (!ctx) return 0;
+    std::lock_guard<std::recursive_mutex> hold(const_cast<zkgpu_ctx *>(ctx)->lock);
     return ctx->msm->shared_table_bytes() + ctx->prover->shared_key_bytes();
 }
 
@@ -209,6 +210,7 @@ int zkgpu_sync(zkgpu_ctx *ctx) {
 
 size_t zkgpu_device_bytes(const zkgpu_ctx *ctx) {
     if (!ctx) return 0;
+    std::lock_guard<std::recursive_mutex> hold(const_cast<zkgpu_ctx *>(ctx)->lock);
     return ctx->ntt->device_bytes() + ctx->msm->device_bytes() + ctx->poly->device_bytes() + ctx->prover->device_bytes() +
            ctx->stage_a.cap + ctx->stage_b.cap;
 }
@@ -690,7 +692,12 @@ int zkgpu_prover_key_poly(zkgpu_ctx *ctx, int which, uint64_t *out) {
     });
 }
 
-size_t zkgpu_prover_key_eval_len(const zkgpu_ctx *ctx) { return ctx && ctx->prover->loaded() ? ctx->prover->eval_len() : 0; }
+size_t zkgpu_prover_key_eval_len(const zkgpu_ctx *ctx) {
+    if (!ctx) return 0;
+    // a key load on another thread rewrites what is read here: same lock as every other entry point
+    std::lock_guard<std::recursive_mutex> hold(const_cast<zkgpu_ctx *>(ctx)->lock);
+    return ctx->prover->loaded() ? ctx->prover->eval_len() : 0;
+}
 
 int zkgpu_prover_key_eval8n(zkgpu_ctx *ctx, int which, uint64_t *out) {
     return guarded(ctx, [&] {
@@ -760,7 +767,9 @@ int zkgpu_prover_force_full_coset(zkgpu_ctx *ctx, int on) {
 }
 
 int zkgpu_prover_last_proof_coset(const zkgpu_ctx *ctx) {
-    if (!ctx || !ctx->prover->proved_once()) return 0;
+    if (!ctx) return 0;
+    std::lock_guard<std::recursive_mutex> hold(const_cast<zkgpu_ctx *>(ctx)->lock);
+    if (!ctx->prover->proved_once()) return 0;
     return ctx->prover->last_proof_half_coset() ? 4 : 8;
 }
 
@@ -943,6 +952,8 @@ int zkgpu_prove(zkgpu_ctx *ctx, const uint64_t *wires, const uint64_t *public_in
             ctx->last_error = proof_rc == ZKGPU_ERR_DEGREE_ZERO    ? "PolynomialDegreeIsZero"
                               : proof_rc == ZKGPU_ERR_DEGREE_LARGE ? "PolynomialDegreeTooLarge"
                                                                    : "quotient polynomial shorter than 3n + 1";
+            t_error = ctx->last_error;   // this thread's copy, taken while the context is still locked
+            t_error_ctx = ctx;
             return;
         }
         for (int i = 0; i < 11; i++) affine_words(proof.comms[i], out_comms_xy + 12 * i, out_comms_infinity + i);
@@ -950,10 +961,6 @@ int zkgpu_prove(zkgpu_ctx *ctx, const uint64_t *wires, const uint64_t *public_in
         if (out_challenges10) memcpy(out_challenges10, proof.challenges, sizeof proof.challenges);
         if (timings8) memcpy(timings8, tm.ms, sizeof tm.ms);
     });
-    if (rc == 0 && proof_rc != 0) {
-        t_error = ctx->last_error;
-        t_error_ctx = ctx;
-    }
     return rc != 0 ? rc : proof_rc;
 }
 

@@ -555,7 +555,7 @@ def run_prove(args, rank, world, local, device):
     if rank == 0 and not sharded and not args.no_sub_records:
         out["with_h2d"] = prove_with_transfers(prover, circ, blinders, n, proof, 1e3 * elapsed / args.steps, max(args.steps // 2, 4))
         out["proofs_in_flight"] = proofs_in_flight(prover, wires, circ, blinders, proof, max(args.steps // 2, 4), elapsed / args.steps)
-        if args.circuit == "widgets" or not args.no_widget_record:
+        if (args.circuit == "widgets" or not args.no_widget_record) and n >= (1 << 14):   # eight rounds of every widget: 2^12 rows
             out["widgets"] = widget_key_record(ctx, n, device, max(args.steps // 3, 3))
             out["rooflines"].append(out["widgets"].pop("roofline"))
 

@@ -5,7 +5,8 @@
 // all select entries of ONE bucket set: sum_i s_i P_i = sum_b (b+1) * sum_{(i,w): |digit_w(s_i)| = b+1} +-T[w][i].
 // There is a single bucket reduction per MSM instead of one per window, and no doubling chain at the end.
 //
-//   1. digits    every scalar leaves Montgomery form and is cut into K signed digits (|digit| <= 2^(c-1));
+//   1. digits    every scalar leaves Montgomery form and is cut into K signed digits (|digit| <= 2^(c-1)); from 2^17
+//                points up the partition passes of the sort do this themselves, in registers, and no digit array exists;
 //   2. sort      counting sort of the n*K (entry, bucket) pairs with per-workgroup histograms in LDS (no global
 //                atomics): count pass, exclusive scan = bucket start offsets, scatter pass writing table indices
 //                (with the digit's sign in bit 31) bucket by bucket.  More than 2^15 buckets are first partitioned
@@ -334,7 +335,7 @@ __device__ __forceinline__ void sort2_block(uint32_t lin, uint32_t S, uint32_t n
 // items by destination in LDS (rank by LDS atomics, exclusive scan of the counts) and then writes them out slot by
 // slot: consecutive lanes store consecutive addresses within a destination's run, so a wavefront's store touches a
 // few lines instead of 64.
-static const uint32_t STAGE_ITEMS = 16384, STAGE_THREADS = 1024;
+static const uint32_t STAGE_THREADS = 1024;
 static const uint32_t STAGE_MAX_BINS = 1024;
 // dynamic LDS for tiles of TILE items: three tables of STAGE_MAX_BINS words, TILE words of payload, TILE bin numbers (16 bit)
 static constexpr uint32_t stage_lds_bytes(uint32_t tile) { return 3 * STAGE_MAX_BINS * 4 + tile * 4 + tile * 2; }
@@ -381,77 +382,111 @@ __global__ void __launch_bounds__(STAGE_THREADS) msm_slice_tasks_kernel(const ui
     if (tid == 0) tasks[0] = total;
 }
 
-// msm_range_kernel<1, .> with staged stores: same mid_key / mid_val contents up to the order inside a block's run.
-// The block of STAGE_ITEMS items (the unit of the count pass) is taken in tiles of TILE.  Tiles of 2^13 items would
-// let two workgroups share a CU; measured slower than one tile of 2^14 (shorter runs), in this pass and in the final
-// one.
-template <uint32_t TILE>
-__global__ void __launch_bounds__(STAGE_THREADS) msm_range_place_kernel(const uint32_t *dig, SortGeom g, uint32_t n_ranges,
-                                                                        uint32_t n_blocks, const uint32_t *blockcnt,
-                                                                        uint32_t *mid_key, uint32_t *mid_val) {
-    constexpr uint32_t PER_THREAD = TILE / STAGE_THREADS;
+// ---- the range partition straight from the scalars ----------------------------------------------------------------
+// The two partition passes above read a digit array that a kernel of its own has written (4 bytes per (scalar, window)
+// pair out, 8 in).  Here a thread takes ONE scalar, leaves Montgomery form, cuts its K <= 16 signed digits and keeps
+// them in registers: the count pass and the placing pass each read the scalars (32 bytes per scalar) and repeat that
+// arithmetic (one field product per scalar), and no digit array exists.  A workgroup owns 1024 consecutive scalars, all
+// their windows: K * 1024 <= 2^14 items, one staged tile.  Item order inside a bucket changes with this (scalar-major
+// per workgroup); the bucket sums do not depend on it.
+static const uint32_t SCALAR_K_MAX = 16;
+__device__ __forceinline__ void scalar_digits(const Fr *scalar, uint32_t c, uint32_t K, uint32_t *dg) {
+    Fr s = Fr::from_mont(gload_fr(scalar));
+    const uint32_t mask = (1u << c) - 1u, half = 1u << (c - 1);
+    uint32_t carry = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < SCALAR_K_MAX; w++) {
+        const uint32_t raw = (s.v[0] & mask) + carry;
+#pragma unroll
+        for (int k = 0; k < 7; k++) s.v[k] = (s.v[k] >> c) | (s.v[k + 1] << (32 - c));
+        s.v[7] >>= c;
+        uint32_t mag = raw, neg = 0;
+        carry = 0;
+        if (raw > half) {
+            mag = (1u << c) - raw;
+            neg = 1;
+            carry = 1;
+        }
+        dg[w] = (w < K && mag) ? (mag | (neg << 31)) : 0u;
+    }
+}
+// count pass: blockcnt[r * n_blocks + blk] = items of workgroup blk's scalars in range r
+__global__ void __launch_bounds__(STAGE_THREADS) msm_range_count_scalars_kernel(const Fr *scalars, SortGeom g, uint32_t c, uint32_t K,
+                                                                                uint32_t n_ranges, uint32_t n_blocks,
+                                                                                uint32_t *blockcnt) {
+    __shared__ uint32_t bins[MAX_RANGES];
+    const uint32_t blk = blockIdx.x, tid = threadIdx.x;
+    if (tid < n_ranges) bins[tid] = 0u;
+    __syncthreads();
+    const uint32_t i = blk * STAGE_THREADS + tid;
+    if (i < g.n) {
+        uint32_t dg[SCALAR_K_MAX];
+        scalar_digits(scalars + i, c, K, dg);
+#pragma unroll
+        for (uint32_t w = 0; w < SCALAR_K_MAX; w++) {
+            const uint32_t mag = dg[w] & 0x7fffffffu;
+            if (mag) atomicAdd(&bins[(mag - 1) >> g.log_range], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < n_ranges) blockcnt[(size_t)tid * n_blocks + blk] = bins[tid];
+}
+// placing pass with staged stores (the workgroup's items are ordered by range in LDS, then stored run by run): mid_key = bucket inside the range | sign << 31,
+// mid_val = table index w * stride + base + i.  (Finding a staged position's range by bisection over the ranges' start
+// offsets instead of the per-position table would let two workgroups share a CU - 76 KiB of LDS each - but measured
+// slower: 2.1 against 1.9 ms for the partition of 2^24 scalars.)
+__global__ void __launch_bounds__(STAGE_THREADS) msm_range_place_scalars_kernel(const Fr *scalars, SortGeom g, uint32_t c, uint32_t K,
+                                                                                uint32_t n_ranges, uint32_t n_blocks,
+                                                                                const uint32_t *blockcnt, uint32_t *mid_key,
+                                                                                uint32_t *mid_val) {
     extern __shared__ uint32_t lds[];
     __shared__ uint32_t wtot[17];
     uint32_t *cnt = lds, *loc = lds + STAGE_MAX_BINS, *gpos = lds + 2 * STAGE_MAX_BINS, *stage = lds + 3 * STAGE_MAX_BINS;
-    uint16_t *sbin = reinterpret_cast<uint16_t *>(stage + TILE);
+    uint16_t *sbin = reinterpret_cast<uint16_t *>(stage + SCALAR_K_MAX * STAGE_THREADS);
     const uint32_t blk = blockIdx.x, tid = threadIdx.x;
     if (tid < n_ranges) {
         cnt[tid] = 0u;
-        gpos[tid] = blockcnt[(size_t)tid * n_blocks + blk];   // where this block's next item of the range goes
+        gpos[tid] = blockcnt[(size_t)tid * n_blocks + blk];   // where this workgroup's items of the range go
     }
     __syncthreads();
     const uint32_t mask = (1u << g.log_range) - 1u;
-    for (uint32_t t0 = 0; t0 < STAGE_ITEMS; t0 += TILE) {
-        const uint32_t lo = blk * STAGE_ITEMS + t0;
-        if (lo >= g.n_items) break;   // uniform
-        uint32_t vv[PER_THREAD], slot[PER_THREAD];
+    const uint32_t i = blk * STAGE_THREADS + tid;
+    uint32_t dg[SCALAR_K_MAX], slot[SCALAR_K_MAX];
+    if (i < g.n) {
+        scalar_digits(scalars + i, c, K, dg);
+    } else {
 #pragma unroll
-        for (uint32_t u = 0; u < PER_THREAD; u++) {
-            const uint32_t j = lo + u * STAGE_THREADS + tid;
-            vv[u] = j < g.n_items ? dig[j] : 0u;
-        }
+        for (uint32_t w = 0; w < SCALAR_K_MAX; w++) dg[w] = 0u;
+    }
 #pragma unroll
-        for (uint32_t u = 0; u < PER_THREAD; u++) {
-            const uint32_t mag = vv[u] & 0x7fffffffu;
-            slot[u] = mag ? atomicAdd(&cnt[(mag - 1) >> g.log_range], 1u) : 0u;
-        }
-        __syncthreads();
-        const uint32_t total = stage_exclusive_scan(cnt, loc, n_ranges, wtot);
-        // keys
+    for (uint32_t w = 0; w < SCALAR_K_MAX; w++) {
+        const uint32_t mag = dg[w] & 0x7fffffffu;
+        slot[w] = mag ? atomicAdd(&cnt[(mag - 1) >> g.log_range], 1u) : 0u;
+    }
+    __syncthreads();
+    const uint32_t total = stage_exclusive_scan(cnt, loc, n_ranges, wtot);
 #pragma unroll
-        for (uint32_t u = 0; u < PER_THREAD; u++) {
-            const uint32_t mag = vv[u] & 0x7fffffffu;
-            if (!mag) continue;
-            const uint32_t b = mag - 1, r = b >> g.log_range;
-            slot[u] += loc[r];
-            stage[slot[u]] = (b & mask) | (vv[u] & 0x80000000u);
-            sbin[slot[u]] = (uint16_t)r;
-        }
-        __syncthreads();
-        for (uint32_t k = tid; k < total; k += STAGE_THREADS) {
-            const uint32_t r = sbin[k];
-            mid_key[gpos[r] + (k - loc[r])] = stage[k];
-        }
-        __syncthreads();
-        // table indexes
+    for (uint32_t w = 0; w < SCALAR_K_MAX; w++) {
+        const uint32_t mag = dg[w] & 0x7fffffffu;
+        if (!mag) continue;
+        const uint32_t b = mag - 1, r = b >> g.log_range;
+        slot[w] += loc[r];
+        stage[slot[w]] = (b & mask) | (dg[w] & 0x80000000u);
+        sbin[slot[w]] = (uint16_t)r;
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < total; k += STAGE_THREADS) {
+        const uint32_t r = sbin[k];
+        mid_key[gpos[r] + (k - loc[r])] = stage[k];
+    }
+    __syncthreads();
 #pragma unroll
-        for (uint32_t u = 0; u < PER_THREAD; u++) {
-            if (!(vv[u] & 0x7fffffffu)) continue;
-            const uint32_t j = lo + u * STAGE_THREADS + tid;
-            const uint32_t w = j / g.n, i = j - w * g.n;
-            stage[slot[u]] = w * g.stride + g.base + i;
-        }
-        __syncthreads();
-        for (uint32_t k = tid; k < total; k += STAGE_THREADS) {
-            const uint32_t r = sbin[k];
-            mid_val[gpos[r] + (k - loc[r])] = stage[k];
-        }
-        __syncthreads();
-        if (tid < n_ranges) {
-            gpos[tid] += cnt[tid];
-            cnt[tid] = 0u;
-        }
-        __syncthreads();
+    for (uint32_t w = 0; w < SCALAR_K_MAX; w++)
+        if (dg[w] & 0x7fffffffu) stage[slot[w]] = w * g.stride + g.base + i;
+    __syncthreads();
+    for (uint32_t k = tid; k < total; k += STAGE_THREADS) {
+        const uint32_t r = sbin[k];
+        mid_val[gpos[r] + (k - loc[r])] = stage[k];
     }
 }
 
@@ -1436,12 +1471,14 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     // sort geometry: up to 2^15 buckets sort in one level (128 KiB of LDS counters per workgroup); above that, ranges
     // of 2^13 buckets, whose output regions (a few MB at 2^20..2^22 points) sit in one XCD's L2 while they are written
     // (measured best among 2^9..2^14 at 2^20 and at 2^24 points); slices so that ~1024 workgroups exist
-    // Between 2^16 and 2^20 buckets the two placing passes stage their stores through LDS (msm_range_place_kernel,
+    // Between 2^16 and 2^20 buckets the two placing passes stage their stores through LDS (msm_range_place_scalars_kernel,
     // msm_sort3_kernel): 1024 ranges of at most 2^10 buckets.  Beyond that the ranges would outgrow the staged
     // kernels' tables: ranges of 2^13 buckets and the lane-scattered kernels.
     const bool staged = log_B > 15 && log_B <= 20;
     const uint32_t log_range = log_B <= 15 ? log_B : staged ? (log_B > 19 ? log_B - 10 : 9) : 13;
-    const uint32_t RANGE_ITEMS = staged ? STAGE_ITEMS : RANGE_PER_THREAD * 256;
+    // the staged partition takes the scalars themselves, 1024 per workgroup with all their windows (K <= 16 there: the
+    // window is at least 17 bits); the other one reads the digit array in blocks of 4096 items
+    const uint32_t RANGE_ITEMS = staged ? STAGE_THREADS * K : RANGE_PER_THREAD * 256;
     const uint32_t n_ranges = 1u << (log_B - log_range);
     uint32_t S_max = 1024 / n_ranges;
     if (S_max < 1) S_max = 1;
@@ -1456,7 +1493,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort2_kernel<1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_range_place_kernel<16384>),
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_range_place_scalars_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, stage_lds_bytes(16384)));
         ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msm_sort3_kernel<16384>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, stage_lds_bytes(16384)));
@@ -1476,7 +1513,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     offsets_.reserve((size_t)nb * 4);
     cursor_.reserve((size_t)nb * S_max * 4);            // per-(sum, slice, bucket) counts, then cursors
     order_.reserve((size_t)nb * 4 + (size_t)m * (N_CLASSES + 1) * 4);
-    digits_.reserve(total_items * 4);
+    if (!staged) digits_.reserve(total_items * 4);
     block_sums_.reserve((size_t)n_scan_blocks * 4 + 4);
     sorted_.reserve(total_items * 4);
     buckets_.reserve((size_t)nb * sizeof(G1Xyzz));
@@ -1544,7 +1581,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     uint32_t *const part_all = cursor_.as<uint32_t>();
     // The small kernels (digits, totals, cursors, schedule, and the one-level sort) cover all sums of the batch in
     // one launch each; the range partition and its sort run per sum.
-    hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(max_len, 256), m), dim3(256), 0, stream_, sums, 0u, c, K);
+    if (!staged) hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(max_len, 256), m), dim3(256), 0, stream_, sums, 0u, c, K);
     mark(1);
     if (n_ranges == 1) {
         mark(2);
@@ -1555,8 +1592,8 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             uint32_t *part = part_all + (size_t)j * part_stride;
             const uint64_t n_items = geom[j].n_items;
             // range partition: count, scan (range-major, one extra entry = the total), place
-            const uint32_t n_blocks = ceil_div(n_items, RANGE_ITEMS), n_cnt = n_ranges * n_blocks + 1;
-            const uint32_t n_cnt_blocks = ceil_div(n_cnt, SCAN_ITEMS);
+            const uint32_t n_blocks = staged ? ceil_div(geom[j].n, STAGE_THREADS) : ceil_div(n_items, RANGE_ITEMS);
+            const uint32_t n_cnt = n_ranges * n_blocks + 1, n_cnt_blocks = ceil_div(n_cnt, SCAN_ITEMS);
             uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
             uint32_t *range_sums = blockcnt + n_cnt;
             uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
@@ -1564,8 +1601,8 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             sums.n_blocks[j] = n_blocks;
             ZK_HIP(hipMemsetAsync(blockcnt + n_cnt - 1, 0, 4, stream_));
             if (staged)
-                hipLaunchKernelGGL((msm_range_kernel<0, STAGE_THREADS>), dim3(n_blocks), dim3(STAGE_THREADS), 0, stream_, dig[j], geom[j],
-                                   n_ranges, n_blocks, blockcnt, mkey, mval);
+                hipLaunchKernelGGL(msm_range_count_scalars_kernel, dim3(n_blocks), dim3(STAGE_THREADS), 0, stream_, sums.scalars[j],
+                                   geom[j], c, K, n_ranges, n_blocks, blockcnt);
             else
                 hipLaunchKernelGGL((msm_range_kernel<0, 256>), dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
                                    blockcnt, mkey, mval);
@@ -1573,8 +1610,8 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream_, range_sums, n_cnt_blocks);
             hipLaunchKernelGGL(scan_add_kernel, dim3(ceil_div(n_cnt, 256)), dim3(256), 0, stream_, blockcnt, range_sums, n_cnt);
             if (staged)
-                hipLaunchKernelGGL(msm_range_place_kernel<16384>, dim3(n_blocks), dim3(STAGE_THREADS), stage_lds_bytes(16384), stream_,
-                                   dig[j], geom[j], n_ranges, n_blocks, blockcnt, mkey, mval);
+                hipLaunchKernelGGL(msm_range_place_scalars_kernel, dim3(n_blocks), dim3(STAGE_THREADS), stage_lds_bytes(16384), stream_,
+                                   sums.scalars[j], geom[j], c, K, n_ranges, n_blocks, blockcnt, mkey, mval);
             else
                 hipLaunchKernelGGL((msm_range_kernel<1, 256>), dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
                                    blockcnt, mkey, mval);
@@ -1610,7 +1647,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     } else {
         for (uint32_t j = 0; j < m; j++) {
             uint32_t *part = part_all + (size_t)j * part_stride;
-            const uint32_t n_blocks = ceil_div(geom[j].n_items, RANGE_ITEMS);
+            const uint32_t n_blocks = staged ? ceil_div(geom[j].n, STAGE_THREADS) : ceil_div(geom[j].n_items, RANGE_ITEMS);
             const uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
             const uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
             if (staged)

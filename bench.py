@@ -55,7 +55,7 @@ MADS_PER_MIXED_ADD = PRODUCTS_PER_MIXED_ADD * FQ28_MADS       # 3666
 # The same addition priced independently of this implementation: 11 field products (the reference's add_mixed,
 # coset-bls12_381/src/g1.rs:701-736) of 2 * 12^2 + 12 = 300 32-bit multiply-accumulates each (CIOS on 12 words).
 ALGORITHMIC_MADS_PER_MIXED_ADD = 11 * 300
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def pmc_row(profile_csv, kernel):
@@ -772,7 +772,7 @@ def proofs_in_flight(prover, wires, circ, blinders, resident_proof, steps, one_a
         clone.close()
 
 
-CPU_BASELINE_RECORD = "r02_cpu_baseline_prove.json"
+CPU_BASELINE_RECORD = "r03_cpu_baseline_prove.json"
 
 
 class progress_lines:
@@ -821,7 +821,7 @@ def oracle_prove_seconds(log_gates, cores):
 def cpu_baseline_prove(log_gates, full=False):
     """Times the oracle's Prover::prove.  By default on a 2^17-gate circuit of the same generator (a bounded sample:
     ten seconds of CPU work) scaled to 2^log_gates by the ratio MEASURED between the two sizes on the same kind of host
-    (profiles/r02_cpu_baseline_prove.json, written by `bench.py --cpu-baseline-full`); with full=True the 2^log_gates
+    (profiles/r03_cpu_baseline_prove.json, written by `bench.py --cpu-baseline-full`); with full=True the 2^log_gates
     proof itself is timed (minutes)."""
     cores = cpu_threads()
     log_s = min(17, log_gates)

@@ -28,6 +28,7 @@
 #include <cmath>
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -691,10 +692,13 @@ __global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t *block_sums, u
 
 __global__ void __launch_bounds__(256) scan_finish_kernel(const uint32_t *counts, uint32_t *offsets,
                                                           const uint32_t *block_sums, uint32_t nb, uint32_t big, MsmTask *tasks,
-                                                          uint32_t *task_count, uint32_t max_tasks) {
+                                                          uint32_t *task_count, uint32_t max_tasks, uint32_t sorted_base,
+                                                          uint32_t key_base) {
+    // counts / offsets: the nb buckets scanned together, which are the buckets key_base ... of the batch; their runs in
+    // `sorted` start at sorted_base
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
-    uint32_t off = offsets[i] + block_sums[i / SCAN_ITEMS];
+    uint32_t off = offsets[i] + block_sums[i / SCAN_ITEMS] + sorted_base;
     offsets[i] = off;
     uint32_t cnt = counts[i];
     if (cnt > big) {
@@ -702,7 +706,7 @@ __global__ void __launch_bounds__(256) scan_finish_kernel(const uint32_t *counts
         uint32_t t0 = atomicAdd(task_count, nt);
         for (uint32_t k = 0; k < nt && t0 + k < max_tasks; k++) {
             MsmTask t;
-            t.key = i;
+            t.key = key_base + i;
             t.start = off + k * BIG_CHUNK;
             t.len = (cnt - k * BIG_CHUNK) < BIG_CHUNK ? (cnt - k * BIG_CHUNK) : BIG_CHUNK;
             t.first = k == 0 ? nt : 0;
@@ -1219,6 +1223,12 @@ struct MsmEngine::TailPool {
 
 MsmEngine::~MsmEngine() {
     delete tail_pool_;
+    if (aux_stream_) {
+        (void)hipStreamSynchronize(aux_stream_);
+        (void)hipStreamDestroy(aux_stream_);
+    }
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
     DevBuf *all[] = {&counts_, &offsets_, &cursor_, &sorted_, &buckets_, &block_sums_, &tasks_, &partials_,
                      &misc_,   &seg_,    &group_sums_, &order_, &digits_, &range_cnt_, &mid_, &slice_tasks_};
     for (DevBuf *b : all) b->release();
@@ -1514,7 +1524,7 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     cursor_.reserve((size_t)nb * S_max * 4);            // per-(sum, slice, bucket) counts, then cursors
     order_.reserve((size_t)nb * 4 + (size_t)m * (N_CLASSES + 1) * 4);
     if (!staged) digits_.reserve(total_items * 4);
-    block_sums_.reserve((size_t)n_scan_blocks * 4 + 4);
+    block_sums_.reserve(2 * ((size_t)n_scan_blocks * 4 + 4));   // two scans at a time when the sorts of a batch overlap
     sorted_.reserve(total_items * 4);
     buckets_.reserve((size_t)nb * sizeof(G1Xyzz));
     tasks_.reserve((size_t)max_tasks * sizeof(MsmTask) + 16);
@@ -1545,7 +1555,6 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     uint32_t **dig = sums.dig;
     uint64_t item_base = 0;
     size_t max_len = 0;
-    uint32_t S_used = 1;
     for (uint32_t j = 0; j < MAX_BATCH; j++) {
         const uint32_t k = j < m ? j : 0;   // unused entries repeat sum 0
         const uint64_t n_items = (uint64_t)lens[k] * K;
@@ -1572,106 +1581,134 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             dig[j] = digits_.as<uint32_t>() + item_base;
             item_base += n_items;
             if (lens[j] > max_len) max_len = lens[j];
-            if (S > S_used) S_used = S;
         } else {
             dig[j] = dig[0];
         }
     }
     const size_t part_stride = (size_t)B * S_max;
     uint32_t *const part_all = cursor_.as<uint32_t>();
-    // The small kernels (digits, totals, cursors, schedule, and the one-level sort) cover all sums of the batch in
-    // one launch each; the range partition and its sort run per sum.
-    if (!staged) hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(max_len, 256), m), dim3(256), 0, stream_, sums, 0u, c, K);
-    mark(1);
-    if (n_ranges == 1) {
-        mark(2);
-        hipLaunchKernelGGL(msm_sort_kernel<0>, dim3(S_used, 1, m), dim3(1024), lds_bytes, stream_, sums, 0u, part_all, part_stride,
-                           sorted_.as<uint32_t>());
-    } else {
-        for (uint32_t j = 0; j < m; j++) {
-            uint32_t *part = part_all + (size_t)j * part_stride;
-            const uint64_t n_items = geom[j].n_items;
-            // range partition: count, scan (range-major, one extra entry = the total), place
-            const uint32_t n_blocks = staged ? ceil_div(geom[j].n, STAGE_THREADS) : ceil_div(n_items, RANGE_ITEMS);
-            const uint32_t n_cnt = n_ranges * n_blocks + 1, n_cnt_blocks = ceil_div(n_cnt, SCAN_ITEMS);
-            uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
-            uint32_t *range_sums = blockcnt + n_cnt;
-            uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
-            sums.range_start[j] = blockcnt;
-            sums.n_blocks[j] = n_blocks;
-            ZK_HIP(hipMemsetAsync(blockcnt + n_cnt - 1, 0, 4, stream_));
-            if (staged)
-                hipLaunchKernelGGL(msm_range_count_scalars_kernel, dim3(n_blocks), dim3(STAGE_THREADS), 0, stream_, sums.scalars[j],
-                                   geom[j], c, K, n_ranges, n_blocks, blockcnt);
-            else
-                hipLaunchKernelGGL((msm_range_kernel<0, 256>), dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
-                                   blockcnt, mkey, mval);
-            hipLaunchKernelGGL(scan_block_kernel, dim3(n_cnt_blocks), dim3(256), 0, stream_, blockcnt, blockcnt, range_sums, n_cnt);
-            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream_, range_sums, n_cnt_blocks);
-            hipLaunchKernelGGL(scan_add_kernel, dim3(ceil_div(n_cnt, 256)), dim3(256), 0, stream_, blockcnt, range_sums, n_cnt);
-            if (staged)
-                hipLaunchKernelGGL(msm_range_place_scalars_kernel, dim3(n_blocks), dim3(STAGE_THREADS), stage_lds_bytes(16384), stream_,
-                                   sums.scalars[j], geom[j], c, K, n_ranges, n_blocks, blockcnt, mkey, mval);
-            else
-                hipLaunchKernelGGL((msm_range_kernel<1, 256>), dim3(n_blocks), dim3(256), 0, stream_, dig[j], geom[j], n_ranges, n_blocks,
-                                   blockcnt, mkey, mval);
-            uint32_t *tasks = nullptr, sort_grid = geom[j].S * n_ranges;
-            if (staged) {
-                sort_grid = n_ranges + (uint32_t)(n_items >> 15) + 1;
-                tasks = slice_tasks_.as<uint32_t>() + (size_t)j * slice_tasks_stride;
-                hipLaunchKernelGGL(msm_slice_tasks_kernel, dim3(1), dim3(STAGE_THREADS), 0, stream_, blockcnt, n_blocks, n_ranges,
-                                   geom[j].S, tasks);
+    // The sort of the sums [first, first + count) of the batch, enqueued on `st`: partition / count pass, the buckets'
+    // offsets (one scan over the count * B buckets, their runs in `sorted` starting at sorted_base), the placing pass and
+    // the schedule.  The small kernels (digits, totals, cursors, schedule, and the one-level sort) cover those sums in one
+    // launch each; the range partition and its sort run per sum.  `bs`: n_scan_blocks + 1 words for the scan.
+    for (uint32_t j = 0; j < m; j++) {
+        if (n_ranges == 1) break;
+        const uint32_t n_blocks = staged ? ceil_div(geom[j].n, STAGE_THREADS) : ceil_div(geom[j].n_items, RANGE_ITEMS);
+        sums.range_start[j] = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
+        sums.n_blocks[j] = n_blocks;
+    }
+    auto sort_sums = [&](uint32_t first, uint32_t count, hipStream_t st, uint32_t *bs, uint32_t sorted_base, bool marks) {
+        auto mark_if = [&](int k) {
+            if (marks) mark(k);
+        };
+        uint32_t s_used = 1;
+        for (uint32_t j = first; j < first + count; j++)
+            if (geom[j].S > s_used) s_used = geom[j].S;
+        if (!staged) hipLaunchKernelGGL(msm_digits_kernel, dim3(ceil_div(max_len, 256), count), dim3(256), 0, st, sums, first, c, K);
+        mark_if(1);
+        if (n_ranges == 1) {
+            mark_if(2);
+            hipLaunchKernelGGL(msm_sort_kernel<0>, dim3(s_used, 1, count), dim3(1024), lds_bytes, st, sums, first, part_all, part_stride,
+                               sorted_.as<uint32_t>());
+        } else {
+            for (uint32_t j = first; j < first + count; j++) {
+                uint32_t *part = part_all + (size_t)j * part_stride;
+                const uint64_t n_items = geom[j].n_items;
+                // range partition: count, scan (range-major, one extra entry = the total), place
+                const uint32_t n_blocks = sums.n_blocks[j];
+                const uint32_t n_cnt = n_ranges * n_blocks + 1, n_cnt_blocks = ceil_div(n_cnt, SCAN_ITEMS);
+                uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
+                uint32_t *range_sums = blockcnt + n_cnt;
+                uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
+                ZK_HIP(hipMemsetAsync(blockcnt + n_cnt - 1, 0, 4, st));
+                if (staged)
+                    hipLaunchKernelGGL(msm_range_count_scalars_kernel, dim3(n_blocks), dim3(STAGE_THREADS), 0, st, sums.scalars[j],
+                                       geom[j], c, K, n_ranges, n_blocks, blockcnt);
+                else
+                    hipLaunchKernelGGL((msm_range_kernel<0, 256>), dim3(n_blocks), dim3(256), 0, st, dig[j], geom[j], n_ranges, n_blocks,
+                                       blockcnt, mkey, mval);
+                hipLaunchKernelGGL(scan_block_kernel, dim3(n_cnt_blocks), dim3(256), 0, st, blockcnt, blockcnt, range_sums, n_cnt);
+                hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, range_sums, n_cnt_blocks);
+                hipLaunchKernelGGL(scan_add_kernel, dim3(ceil_div(n_cnt, 256)), dim3(256), 0, st, blockcnt, range_sums, n_cnt);
+                if (staged)
+                    hipLaunchKernelGGL(msm_range_place_scalars_kernel, dim3(n_blocks), dim3(STAGE_THREADS), stage_lds_bytes(16384), st,
+                                       sums.scalars[j], geom[j], c, K, n_ranges, n_blocks, blockcnt, mkey, mval);
+                else
+                    hipLaunchKernelGGL((msm_range_kernel<1, 256>), dim3(n_blocks), dim3(256), 0, st, dig[j], geom[j], n_ranges, n_blocks,
+                                       blockcnt, mkey, mval);
+                uint32_t *tasks = nullptr, sort_grid = geom[j].S * n_ranges;
+                if (staged) {
+                    sort_grid = n_ranges + (uint32_t)(n_items >> 15) + 1;
+                    tasks = slice_tasks_.as<uint32_t>() + (size_t)j * slice_tasks_stride;
+                    hipLaunchKernelGGL(msm_slice_tasks_kernel, dim3(1), dim3(STAGE_THREADS), 0, st, blockcnt, n_blocks, n_ranges,
+                                       geom[j].S, tasks);
+                }
+                if (m == 1) mark_if(2);   // with several sums the partitions and count passes alternate: all of it counts as partition
+                // the placing pass advanced nothing in global memory: blockcnt still holds the start positions
+                hipLaunchKernelGGL(msm_sort2_kernel<0>, dim3(sort_grid), dim3(1024), lds_bytes, st, mkey, mval, blockcnt, n_blocks,
+                                   geom[j], tasks, part, sorted_.as<uint32_t>());
             }
-            if (m == 1) mark(2);   // with several sums the partitions and count passes alternate: all of it counts as partition
-            // msm_range_kernel<1> advanced nothing in global memory: blockcnt still holds the start positions
-            hipLaunchKernelGGL(msm_sort2_kernel<0>, dim3(sort_grid), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt, n_blocks,
-                               geom[j], tasks, part, sorted_.as<uint32_t>());
+            if (m > 1) mark_if(2);
         }
-        if (m > 1) mark(2);
-    }
-    mark(3);
-    hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(B, 256), m), dim3(256), 0, stream_, sums, 0u, part_all, part_stride,
-                       counts_.as<uint32_t>());
-    // one scan over all m * B buckets: every bucket's run in `sorted`
-    hipLaunchKernelGGL(scan_block_kernel, dim3(n_scan_blocks), dim3(256), 0, stream_, counts_.as<uint32_t>(),
-                       offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream_, block_sums_.as<uint32_t>(), n_scan_blocks);
-    hipLaunchKernelGGL(scan_finish_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, stream_, counts_.as<uint32_t>(),
-                       offsets_.as<uint32_t>(), block_sums_.as<uint32_t>(), nb, big, tasks_.as<MsmTask>(), task_count, max_tasks);
-    hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(B, 256), m), dim3(256), 0, stream_, sums, 0u, part_all, part_stride,
-                       offsets_.as<uint32_t>());
-    mark(4);
-    if (n_ranges == 1) {
-        hipLaunchKernelGGL(msm_sort_kernel<1>, dim3(S_used, 1, m), dim3(1024), lds_bytes, stream_, sums, 0u, part_all, part_stride,
-                           sorted_.as<uint32_t>());
-    } else {
-        for (uint32_t j = 0; j < m; j++) {
-            uint32_t *part = part_all + (size_t)j * part_stride;
-            const uint32_t n_blocks = staged ? ceil_div(geom[j].n, STAGE_THREADS) : ceil_div(geom[j].n_items, RANGE_ITEMS);
-            const uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
-            const uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
-            if (staged)
-                hipLaunchKernelGGL(msm_sort3_kernel<16384>, dim3(n_ranges + (geom[j].n_items >> 15) + 1), dim3(STAGE_THREADS),
-                                   stage_lds_bytes(16384), stream_, mkey, mval, blockcnt, n_blocks, geom[j],
-                                   slice_tasks_.as<uint32_t>() + (size_t)j * slice_tasks_stride, part, sorted_.as<uint32_t>());
-            else
-                hipLaunchKernelGGL(msm_sort2_kernel<1>, dim3(geom[j].S * n_ranges), dim3(1024), lds_bytes, stream_, mkey, mval, blockcnt,
-                                   n_blocks, geom[j], nullptr, part, sorted_.as<uint32_t>());
+        mark_if(3);
+        const uint32_t nb_sub = count * B, n_sub_blocks = ceil_div(nb_sub, SCAN_ITEMS);
+        uint32_t *counts = counts_.as<uint32_t>() + (size_t)first * B, *offsets = offsets_.as<uint32_t>() + (size_t)first * B;
+        hipLaunchKernelGGL(msm_totals_kernel, dim3(ceil_div(B, 256), count), dim3(256), 0, st, sums, first, part_all, part_stride,
+                           counts_.as<uint32_t>());
+        // one scan over these sums' buckets: every bucket's run in `sorted`
+        hipLaunchKernelGGL(scan_block_kernel, dim3(n_sub_blocks), dim3(256), 0, st, counts, offsets, bs, nb_sub);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, bs, n_sub_blocks);
+        hipLaunchKernelGGL(scan_finish_kernel, dim3(ceil_div(nb_sub, 256)), dim3(256), 0, st, counts, offsets, bs, nb_sub, big,
+                           tasks_.as<MsmTask>(), task_count, max_tasks, sorted_base, first * B);
+        hipLaunchKernelGGL(msm_cursors_kernel, dim3(ceil_div(B, 256), count), dim3(256), 0, st, sums, first, part_all, part_stride,
+                           offsets_.as<uint32_t>());
+        mark_if(4);
+        if (n_ranges == 1) {
+            hipLaunchKernelGGL(msm_sort_kernel<1>, dim3(s_used, 1, count), dim3(1024), lds_bytes, st, sums, first, part_all, part_stride,
+                               sorted_.as<uint32_t>());
+        } else {
+            for (uint32_t j = first; j < first + count; j++) {
+                uint32_t *part = part_all + (size_t)j * part_stride;
+                const uint32_t n_blocks = sums.n_blocks[j];
+                const uint32_t *blockcnt = range_cnt_.as<uint32_t>() + (size_t)j * range_cnt_stride;
+                const uint32_t *mkey = mid_.as<uint32_t>() + (size_t)j * 2 * max_items, *mval = mkey + max_items;
+                if (staged)
+                    hipLaunchKernelGGL(msm_sort3_kernel<16384>, dim3(n_ranges + (geom[j].n_items >> 15) + 1), dim3(STAGE_THREADS),
+                                       stage_lds_bytes(16384), st, mkey, mval, blockcnt, n_blocks, geom[j],
+                                       slice_tasks_.as<uint32_t>() + (size_t)j * slice_tasks_stride, part, sorted_.as<uint32_t>());
+                else
+                    hipLaunchKernelGGL(msm_sort2_kernel<1>, dim3(geom[j].S * n_ranges), dim3(1024), lds_bytes, st, mkey, mval, blockcnt,
+                                       n_blocks, geom[j], nullptr, part, sorted_.as<uint32_t>());
+            }
         }
-    }
-    mark(5);
-    // schedule: class histogram, scan, placement
-    if (small_schedule) {
-        hipLaunchKernelGGL(msm_schedule_small_kernel, dim3(m), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B, class_shift, big,
-                           class_cursor, order);
-    } else {
-        hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024), m), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
-                           class_shift, big, class_cursor, order, 0u);
-        hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(m), dim3(64), 0, stream_, class_cursor, 0u);
-        hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024), m), dim3(1024), 0, stream_, counts_.as<uint32_t>(), B,
-                           class_shift, big, class_cursor, order, 0u);
-    }
-    mark(6);
+        mark_if(5);
+        // schedule: class histogram, scan, placement
+        if (small_schedule) {
+            hipLaunchKernelGGL(msm_schedule_small_kernel, dim3(count), dim3(1024), 0, st, counts, B, class_shift, big,
+                               class_cursor + (size_t)first * (N_CLASSES + 1), order + (size_t)first * B);
+        } else {
+            hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024), count), dim3(1024), 0, st, counts_.as<uint32_t>(), B,
+                               class_shift, big, class_cursor, order, first);
+            hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(count), dim3(64), 0, st, class_cursor, first);
+            hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024), count), dim3(1024), 0, st, counts_.as<uint32_t>(), B,
+                               class_shift, big, class_cursor, order, first);
+        }
+        mark_if(6);
+    };
+    auto accumulate_sums = [&](uint32_t first, uint32_t count, uint32_t log_p, bool fused) {
+        const dim3 grid(ceil_div((uint64_t)B << log_p, 256), fused ? count : 1);
+        for (uint32_t j = first; j < (fused ? first + 1 : first + count); j++) {
+            auto launch = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream_, table, sorted_.as<uint32_t>(), offsets_.as<uint32_t>(),
+                                   counts_.as<uint32_t>(), order, class_cursor, buckets_.as<G1Xyzz>(), B, j);
+            };
+            if (log_p == 0) launch(msm_accumulate_kernel<0>);
+            else if (log_p == 1) launch(msm_accumulate_kernel<1>);
+            else if (log_p == 2) launch(msm_accumulate_kernel<2>);
+            else if (log_p == 3) launch(msm_accumulate_kernel<3>);
+            else launch(msm_accumulate_kernel<4>);
+        }
+    };
     // Up to 2^15 buckets per sum the launch is bound by the longest chain of additions on one lane, not by throughput:
     // the sums of a batch then share one launch, and two or more lanes share each bucket while the chains are worth
     // cutting (measured on 2^15-gate proofs: 8.8 ms with one lane per bucket and one launch per sum, 6.1 ms this way).
@@ -1687,19 +1724,30 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
     // (a full addition per halving, executed by the whole wave) are then dearer than the chains they shorten (2^15-gate
     // proof, four sums per launch: 3.88 ms with four lanes per bucket, 3.77 with two, 4.12 with one)
     while (log_p > 0 && ((uint64_t)m * B << log_p) > 262144) log_p--;
-    {
-        const dim3 grid(ceil_div((uint64_t)B << log_p, 256), fused ? m : 1);
-        for (uint32_t j = 0; j < (fused ? 1u : m); j++) {
-            auto launch = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, grid, dim3(256), 0, stream_, table, sorted_.as<uint32_t>(), offsets_.as<uint32_t>(),
-                                   counts_.as<uint32_t>(), order, class_cursor, buckets_.as<G1Xyzz>(), B, j);
-            };
-            if (log_p == 0) launch(msm_accumulate_kernel<0>);
-            else if (log_p == 1) launch(msm_accumulate_kernel<1>);
-            else if (log_p == 2) launch(msm_accumulate_kernel<2>);
-            else if (log_p == 3) launch(msm_accumulate_kernel<3>);
-            else launch(msm_accumulate_kernel<4>);
+    // With several sums over 2^16 buckets or more, the accumulation of the first sum (bound by the integer pipeline) runs
+    // beside the sort of the others (bound by memory and LDS latency) on a second stream; only the first sum's sort is
+    // then exposed.  Both streams are joined again before the remaining accumulations.  Phase timing (profile_) keeps
+    // everything on one stream.
+    static const bool overlap_off = getenv("ZKGPU_MSM_NO_OVERLAP") != nullptr;   // for A/B measurements
+    const bool overlap = staged && m >= 2 && !fused && !profile_ && !overlap_off;
+    if (overlap) {
+        if (!aux_stream_) {
+            ZK_HIP(hipStreamCreateWithFlags(&aux_stream_, hipStreamNonBlocking));   // (its priority made no difference)
+            ZK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+            ZK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
         }
+        uint32_t *bs = block_sums_.as<uint32_t>();
+        ZK_HIP(hipEventRecord(ev_fork_, stream_));            // behind the clears above and whatever used the buffers before
+        ZK_HIP(hipStreamWaitEvent(aux_stream_, ev_fork_, 0));
+        sort_sums(1, m - 1, aux_stream_, bs + n_scan_blocks + 1, geom[0].n_items, false);
+        ZK_HIP(hipEventRecord(ev_join_, aux_stream_));
+        sort_sums(0, 1, stream_, bs, 0, false);
+        accumulate_sums(0, 1, log_p, false);
+        ZK_HIP(hipStreamWaitEvent(stream_, ev_join_, 0));
+        accumulate_sums(1, m - 1, log_p, false);
+    } else {
+        sort_sums(0, m, stream_, block_sums_.as<uint32_t>(), 0, true);
+        accumulate_sums(0, m, log_p, fused);
     }
     mark(7);
     const uint32_t big_grid = max_tasks < 2048 ? max_tasks : 2048;

@@ -81,6 +81,9 @@ class MsmEngine {
 
    private:
     hipStream_t stream_;
+    // second stream for the sorts of a batch's later sums, which run beside the first sum's accumulation
+    hipStream_t aux_stream_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     void build_table(size_t n);
 
     // The resident points: owned by `table_`, which engines on one GPU may share; points_ and table28_ are this engine's

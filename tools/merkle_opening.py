@@ -105,13 +105,19 @@ def service(contexts, height, tree, positions, circ, label, tau, gxy, root, veri
     from zkvm_amd import api, circuits, poseidon as P
     n = circ["n"]
     sxy, sinf, h, tau_h = verifier_side
-    workers = []
-    for _ in range(contexts):
-        ctx = zkvm_amd.Context(0)
-        ctx.srs_setup(tau, gxy, n + 7)
-        gp = api.Prover(ctx, n, circ["constraints"], circ["selectors"].reshape(-1, 4), label, circ["pi_indexes"])
-        ctx.sync()
-        workers.append((ctx, gp))
+    # one context loads the SRS and the key; the others are clones of it (zkgpu_ctx_clone = the reference's
+    # `#[derive(Clone)] Prover`): a stream and per-proof buffers each, one SRS table and one key on the GPU
+    first = zkvm_amd.Context(0)
+    first.srs_setup(tau, gxy, n + 7)
+    gp0 = api.Prover(first, n, circ["constraints"], circ["selectors"].reshape(-1, 4), label, circ["pi_indexes"])
+    first.sync()
+    workers = [(first, gp0)]
+    for _ in range(contexts - 1):
+        ctx = first.clone()
+        workers.append((ctx, gp0.on(ctx)))
+    print("%d contexts: %.2f GiB of table and key held once, %.2f GiB of buffers per clone" % (
+        contexts, first.device_bytes_shared() / 2.0**30,
+        (workers[-1][0].device_bytes() - workers[-1][0].device_bytes_shared()) / 2.0**30), flush=True)
     openings = [(tree.opening(p), tree.leaves[p]) for p in positions]
     last = [None] * contexts
 

@@ -66,7 +66,7 @@ int zkgpu_init(zkgpu_ctx **out, int device_id);
 void zkgpu_destroy(zkgpu_ctx *ctx);
 /* #[derive(Clone)] Prover (plonk/src/compiler/prover.rs:20-21): a second context on the same GPU, with a stream and
  * per-proof buffers of its own, that refers to the SRS table and the prover key `src` holds instead of copying them (at
- * 2^20 gates 2.9 GiB of table and 2.7 GiB of key stay single).  Both are read-only after their load, so the clones
+ * 2^20 gates 4.8 GiB of table and key together stay single).  Both are read-only after their load, so the clones
  * prove concurrently, one host thread each, with no lock between them; the shared data lives until the last context
  * that refers to it is destroyed or loads something else (a load replaces only that context's reference).  Coset
  * vectors `src` built lazily after its key load, twiddle tables and all scratch are per context.  Not for a key

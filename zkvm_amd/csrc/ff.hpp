@@ -331,7 +331,7 @@ struct FrParams {
     // unsaturated form used inside mul: 9 limbs of 29 bits, radix 2^261 = 2^256 * 2^5
     static constexpr int UL = 29, UN = 9, USH = 5;
     static constexpr uint32_t UINV = 0x1fffffffu;   // -r^-1 mod 2^29
-    FF_HD static uint32_t umod(int i) {
+    FF_HD static constexpr uint32_t umod(int i) {
         constexpr uint32_t M[9] = {0x00000001u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu,
                                    0x0c0404d0u, 0x1520cce7u, 0x0a6533afu, 0x0073eda7u};
         return M[i];

@@ -264,53 +264,7 @@ void PolyEngine::take_even(const Fr *src, uint64_t count, Fr *dst) {
 }
 
 // ---- quotient -----------------------------------------------------------------------------------------------
-// The quotient kernel evaluates ~30 (arithmetic-only circuits) to ~150 field products per point; one out-of-line
-// product keeps the kernel inside the instruction cache.
-static __device__ __noinline__ Fr fr_mul_outlined(Fr a, Fr b) { return Fr::mul(a, b); }
-struct OutlinedMul {
-    __device__ __forceinline__ static Fr mul(const Fr &a, const Fr &b) { return fr_mul_outlined(a, b); }
-};
-#define FM(a, b) fr_mul_outlined((a), (b))
-
-// The range, logic, fixed-base and curve-addition terms (widget `compute_quotient_i`, each multiplied by its selector
-// and its separation challenge) are evaluated by a launch of their own per widget whose selector polynomial is not
-// identically zero, and summed per point in `sum`; quotient_limb_kernel adds that sum to the arithmetic and permutation
-// terms.  Field addition is exact, so the order of the terms does not show in the result.  One kernel with every widget
-// compiled in needs all 256 VGPRs and runs one wave per SIMD, which leaves nothing to hide the latency of its two dozen
-// streams; a widget alone needs under half of that.
-//   W = 0 range/proverkey.rs:31-59, 1 logic/proverkey.rs:34-78, 2 ecc/scalar_mul/fixed_base/proverkey.rs:38-101,
-//   3 ecc/curve_addition/proverkey.rs:32-83
-template <int W>
-__global__ void __launch_bounds__(256) quotient_widget_kernel(QuotientArgs q, Fr *sum, bool first) {
-    typedef OutlinedMul M;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= q.n8) return;
-    const uint32_t iw = (i + q.rot) & (q.n8 - 1);  // "next row" on the 8n coset (quotient_poly.rs:53-59,134-136)
-    const Fr a = ld(q.a + i), b = ld(q.b + i), c = ld(q.c + i), d = ld(q.d + i);
-    const Fr d_w = ld(q.d + iw);
-    Fr t;
-    if (W == 0) {
-        const Fr s = w_range_identity<M>(q.sep_k[0], a, b, c, d, d_w);
-        t = FM(FM(s, ld(q.sel[Q_RANGE] + i)), q.range_ch);
-    } else {
-        const Fr a_w = ld(q.a + iw), b_w = ld(q.b + iw);
-        if (W == 1) {
-            const Fr s = w_logic_identity<M>(q.sep_k[1], a, a_w, b, b_w, c, d, d_w, ld(q.sel[Q_C] + i));
-            t = FM(FM(ld(q.sel[Q_LOGIC] + i), s), q.logic_ch);
-        } else if (W == 2) {
-            const Fr s = w_fixed_base_identity<M>(q.sep_k[2], a, a_w, b, b_w, c, d, d_w, ld(q.sel[Q_L] + i), ld(q.sel[Q_R] + i),
-                                                  ld(q.sel[Q_C] + i));
-            t = FM(FM(s, ld(q.sel[Q_FIXED] + i)), q.fixed_ch);
-        } else {
-            const Fr s = w_curve_add_identity<M>(q.sep_k[3], a, a_w, b, b_w, c, d, d_w);
-            t = FM(FM(s, ld(q.sel[Q_VAR] + i)), q.var_ch);
-        }
-    }
-    if (!first) t = Fr::add(t, ld(sum + i));
-    st(sum + i, t);
-}
-
-// ---- the same identity on unsaturated limbs, for circuits with the arithmetic and permutation terms only ---------
+// ---- the gate identities on unsaturated limbs ----------------------------------------------------------------------
 // Every operand is unpacked once into nine 29-bit limbs and stays there: sums are plain limb additions without a
 // modular correction, differences add a multiple of r first, and only the one stored result is brought back to
 // canonical form.  A product x * (32 y) / 2^261 = x y / 2^256 keeps the Montgomery scaling when its right operand
@@ -326,7 +280,7 @@ static __device__ __forceinline__ L9 l9_mul(L9 x, L9 y) {
     Fr::mul_limbs(x.v, y.v, r.v);
     return r;
 }
-#define LM(x, y) l9_mul((x), (y))
+static __device__ __forceinline__ L9 LM(const L9 &x, const L9 &y) { return l9_mul(x, y); }
 __device__ __forceinline__ L9 l9(const Fr &x) {      // the integer x
     L9 r;
     Fr::unpack(x, r.v, 0);
@@ -348,6 +302,167 @@ __device__ __forceinline__ L9 l9_small(const L9 &x, uint32_t k) {
     L9 r;
     u9_small_mul(x.v, k, r.v);
     return r;
+}
+
+// ---- widget terms ------------------------------------------------------------------------------------------------
+// The range, logic, fixed-base and curve-addition terms (widget `compute_quotient_i`, each multiplied by its selector
+// and its separation challenge) are evaluated by a launch of their own per widget whose selector polynomial is not
+// identically zero, and summed per point in `sum`; quotient_limb_kernel adds that sum to the arithmetic and permutation
+// terms.  Field addition is exact, so neither the order of the terms nor the way a term is factored shows in the
+// (canonical) result.
+//   W = 0 range/proverkey.rs:31-59, 1 logic/proverkey.rs:34-78, 2 ecc/scalar_mul/fixed_base/proverkey.rs:38-101,
+//   3 ecc/curve_addition/proverkey.rs:32-83
+// These kernels work on "scaled" values: x is carried as an integer congruent to 32 x.  The limb product of two
+// scaled values, (32 x)(32 y) / 2^261 = 32 (x y / 2^256), is the scaled Montgomery product, so chains of products
+// need no factor of their own; a wire value is scaled for free while it is unpacked (shift 5), constants arrive scaled
+// and canonical (below r) from the host, and the last product, by the unscaled selector, returns to the plain form.
+// Bounds in the comments are in units of r, rho = 2^261 / r = 76.5 as above; l9_red brings any value below 2^263 to
+// below 1.01 (the quotient estimate of u9_qreduce leaves less than r + (q + 1) 2^232).
+
+// M r with every limb below the top raised by RAISE * 2^29, borrowed from the limb above: x + (bias - y) is x - y + M r
+// limb by limb, without a borrow, for y with limbs below RAISE * 2^29 and a value below (M - 1) r.  x's limbs must
+// leave room: below 2^32 - (RAISE + 1) 2^29.
+template <uint32_t M, uint32_t RAISE>
+struct U9Bias {
+    uint32_t v[9];
+    constexpr U9Bias() : v{} {
+        uint64_t c = 0;
+        for (int k = 0; k < 9; k++) {
+            c += (uint64_t)M * FrParams::umod(k);
+            v[k] = k < 8 ? (uint32_t)c & U9_MASK : (uint32_t)c;
+            c >>= 29;
+        }
+        for (int k = 0; k < 8; k++) {
+            v[k] += RAISE << 29;
+            v[k + 1] -= RAISE;
+        }
+    }
+};
+template <uint32_t M, uint32_t RAISE>
+static __device__ __forceinline__ L9 l9_sub(const L9 &x, const L9 &y) {   // x - y + M r, not normalised
+    constexpr U9Bias<M, RAISE> B;
+    L9 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.v[k] = x.v[k] + (B.v[k] - y.v[k]);
+    return r;
+}
+static __device__ __forceinline__ L9 l9_add(const L9 &x, const L9 &y) {
+    L9 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.v[k] = x.v[k] + y.v[k];
+    return r;
+}
+static __device__ __forceinline__ L9 l9_shl(const L9 &x, int s) {         // 2^s x, limb by limb
+    L9 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.v[k] = x.v[k] << s;
+    return r;
+}
+static __device__ __forceinline__ L9 l9_norm(L9 x) {
+    u9_normalize(x.v);
+    return x;
+}
+static __device__ __forceinline__ L9 l9_red(L9 x) {                        // any limbs, below 2^263 -> normalised, below 1.01
+    u9_normalize(x.v);
+    u9_qreduce(x.v);
+    return x;
+}
+// scaled x - 4 y of two wire values (range/proverkey.rs:44-56, logic/proverkey.rs:57-63): below 32 + 256 -> below 1.01
+static __device__ __forceinline__ L9 w_quad_diff(const Fr &x, const Fr &y) {
+    return l9_red(l9_sub<256, 4>(l9x32(x), l9_shl(l9x32(y), 2)));
+}
+// scaled f (f - 1)(f - 2)(f - 3) = u (u + 2) with u = f^2 - 3 f (range/proverkey.rs:92-97, logic/proverkey.rs:124-129),
+// f scaled, normalised and below 1.01: below 2.19
+static __device__ __forceinline__ L9 w_delta_scaled(const L9 &f, const L9 &two32) {
+    const L9 u = l9_norm(l9_sub<8, 1>(LM(f, f), l9_small(f, 3)));          // 1.02 - 3.03 + 8: below 9.02
+    return LM(u, l9_add(u, two32));                                        // 9.02 * 10.02 / rho + 1
+}
+// the widget's term, scaled and below 82 with any limbs -> times the selector and the scaled challenge, plus the terms
+// summed so far, canonical
+static __device__ __forceinline__ void w_finish(const L9 &s, const Fr &selector, const Fr &ch32, Fr *sum, uint32_t i, bool first) {
+    L9 t = LM(LM(l9_norm(s), l9(selector)), l9(ch32));                     // below 2.08 -> below 1.03, plain form
+    if (!first) u9_add(t.v, l9(ld(sum + i)).v);                            // below 2.03
+    t = l9_red(t);
+    Fr::cond_sub_limbs(t.v);
+    st(sum + i, Fr::pack(t.v));
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) quotient_widget_kernel(QuotientArgs q, Fr *sum, bool first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.n8) return;
+    const uint32_t iw = (i + q.rot) & (q.n8 - 1);  // "next row" on the 8n coset (quotient_poly.rs:53-59,134-136)
+    const QuotientArgs::WidgetConsts &wc = q.wc[W];
+    if constexpr (W == 0) {
+        // delta(c - 4d) + kappa delta(b - 4c) + kappa^2 delta(a - 4b) + kappa^3 delta(d_w - 4a), by Horner's rule
+        const Fr a = ld(q.a + i), b = ld(q.b + i), c = ld(q.c + i), d = ld(q.d + i);
+        const L9 two32 = l9(q.two32), k = l9(wc.k32[0]);
+        L9 s = w_delta_scaled(w_quad_diff(ld(q.d + iw), a), two32);        // below 2.19
+        s = l9_add(LM(s, k), w_delta_scaled(w_quad_diff(a, b), two32));    // 1.03 + 2.19, limbs below 2^30
+        s = l9_add(LM(s, k), w_delta_scaled(w_quad_diff(b, c), two32));    // 1.05 + 2.19
+        s = l9_add(LM(s, k), w_delta_scaled(w_quad_diff(c, d), two32));    // below 3.24
+        w_finish(s, ld(q.sel[Q_RANGE] + i), wc.ch32, sum, i, first);
+    } else if constexpr (W == 1) {
+        const L9 two32 = l9(q.two32);
+        const L9 ai = w_quad_diff(ld(q.a + iw), ld(q.a + i)), bi = w_quad_diff(ld(q.b + iw), ld(q.b + i));
+        const L9 di = w_quad_diff(ld(q.d + iw), ld(q.d + i));              // each below 1.01
+        const L9 w = l9x32(ld(q.c + i));                                    // below 32
+        L9 s = w_delta_scaled(ai, two32);                                   // c_0: below 2.19
+        u9_add(s.v, LM(w_delta_scaled(bi, two32), l9(wc.k32[0])).v);        // c_1: below 1.03
+        u9_add(s.v, LM(w_delta_scaled(di, two32), l9(wc.k32[1])).v);        // c_2: below 1.03
+        u9_add(s.v, LM(l9_sub<4, 1>(w, LM(ai, bi)), l9(wc.k32[2])).v);      // c_3 = kappa^3 (c - a b): 36 / rho + 1 = 1.47
+        // logic/proverkey.rs:132-155 with a, b, w, c = ai, bi, c, di
+        const L9 ab = l9_add(ai, bi);                                       // below 2.02, limbs below 2^30
+        const L9 ab_n = l9_norm(ab);
+        // 4 w - 18 (a + b) + 81: below 128 + 64 + 1
+        const L9 inner = l9_red(l9_add(l9_sub<64, 1>(l9_shl(w, 2), l9_small(ab, 18)), l9(q.c81_32)));
+        const L9 sq = l9_small(l9_add(LM(ai, ai), LM(bi, bi)), 18);         // 18 (a^2 + b^2): below 36.8, normalised
+        // w inner + 18 (a^2 + b^2) - 81 (a + b) + 83: below 1.42 + 36.8 + 256 + 1
+        const L9 f1 = l9_red(l9_add(l9_add(LM(w, inner), sq), l9_sub<256, 1>(l9(q.c83_32), l9_small(ab_n, 81))));
+        const L9 f2 = LM(w, f1);                                            // F: below 32 * 1.01 / rho + 1 = 1.43
+        // E = 3 (a + b + c) - 2 F: below 9.1 + 8
+        const L9 e = l9_sub<8, 2>(l9_small(l9_add(ab, di), 3), l9_shl(f2, 1));
+        // B = q_c (9 c - 3 (a + b)): (9.1 + 8) * 32 / rho + 1 = 8.2
+        const L9 bq = LM(l9_sub<8, 1>(l9_small(di, 9), l9_small(ab_n, 3)), l9x32(ld(q.sel[Q_C] + i)));
+        u9_add(s.v, LM(l9_norm(l9_add(bq, e)), l9(wc.k32[3])).v);           // c_4: 25.3 / rho + 1; s below 7.1
+        w_finish(s, ld(q.sel[Q_LOGIC] + i), wc.ch32, sum, i, first);
+    } else if constexpr (W == 2) {
+        const L9 one32 = l9(q.one32);
+        const L9 a32 = l9x32(ld(q.a + i)), b32 = l9x32(ld(q.b + i));
+        const Fr c = ld(q.c + i);
+        // bit = d_w - 2 d (fixed_base/proverkey.rs:160-162): below 32 + 128 -> 1.01
+        const L9 bit = l9_red(l9_sub<128, 2>(l9x32(ld(q.d + iw)), l9_shl(l9x32(ld(q.d + i)), 1)));
+        const L9 bb = LM(bit, bit);                                         // below 1.02
+        L9 s = LM(bit, l9_sub<4, 1>(bb, one32));                            // bit (bit - 1)(bit + 1) = bit (bit^2 - 1): 1.07
+        // y_alpha = bit^2 (q_r - 1) + 1: 1.02 * 36 / rho + 2 = 2.48, limbs below 2^30
+        const L9 ya = l9_add(LM(bb, l9_sub<4, 1>(l9x32(ld(q.sel[Q_R] + i)), one32)), one32);
+        const L9 xa = LM(bit, l9x32(ld(q.sel[Q_L] + i)));                   // x_alpha = bit q_l: below 1.43
+        // kappa (bit q_c - c): the difference in plain form (1.02 + 4 - c), back to the scaled one through 1024 kappa
+        u9_add(s.v, LM(l9_sub<4, 1>(LM(bit, l9(ld(q.sel[Q_C] + i))), l9(c)), l9(wc.k1024)).v);   // below 1.07
+        const L9 dxy = LM(LM(LM(l9x32(c), a32), b32), l9(q.edwards_d32));   // d c a b: 14.4 -> 7.03 -> 1.1
+        const L9 x_lhs = LM(l9x32(ld(q.a + iw)), l9_add(dxy, one32));       // a_w (1 + d x y): 32 * 2.1 / rho + 1 = 1.88
+        const L9 x_rhs = l9_add(LM(a32, ya), LM(b32, xa));                  // 2.04 + 1.6, limbs below 2^30
+        u9_add(s.v, LM(l9_sub<5, 2>(x_lhs, x_rhs), l9(wc.k32[1])).v);       // kappa^2 (lhs - rhs): 6.9 / rho + 1
+        const L9 y_lhs = LM(l9x32(ld(q.b + iw)), l9_sub<4, 1>(one32, dxy)); // b_w (1 - d x y): 32 * 5 / rho + 1 = 3.1
+        const L9 y_rhs = l9_add(LM(b32, ya), LM(a32, xa));
+        u9_add(s.v, LM(l9_sub<5, 2>(y_lhs, y_rhs), l9(wc.k32[2])).v);       // kappa^3 (lhs - rhs): 8.1 / rho + 1; s below 4.4
+        w_finish(s, ld(q.sel[Q_FIXED] + i), wc.ch32, sum, i, first);
+    } else {
+        // x1 = a, y1 = b, x2 = c, y2 = d, x3 = a_w, y3 = b_w, x1 y2 = d_w
+        const L9 one32 = l9(q.one32);
+        const L9 a32 = l9x32(ld(q.a + i)), b32 = l9x32(ld(q.b + i)), c32 = l9x32(ld(q.c + i)), d32 = l9x32(ld(q.d + i));
+        const L9 dw32 = l9x32(ld(q.d + iw));
+        const L9 y1x2 = LM(b32, c32);                                       // products of two wire values: below 14.4
+        const L9 dd = LM(LM(l9(q.edwards_d32), dw32), y1x2);                // d x1 y2 y1 x2: 1.42 -> 1.27
+        L9 s = l9_sub<64, 1>(LM(a32, d32), dw32);                           // x1 y2 - d_w: below 14.4 + 64
+        // kappa (d_w + y1 x2 - x3 (1 + dd)): 32 + 14.4 + 4 = 50.4 -> 1.66
+        const L9 x3 = LM(l9x32(ld(q.a + iw)), l9_add(dd, one32));           // 32 * 2.27 / rho + 1 = 1.95
+        u9_add(s.v, LM(l9_norm(l9_sub<4, 1>(l9_add(dw32, y1x2), x3)), l9(wc.k32[0])).v);
+        // kappa^2 (y1 y2 + x1 x2 - y3 (1 - dd)): 14.4 + 14.4 + 4 -> 1.43
+        const L9 y3 = LM(l9x32(ld(q.b + iw)), l9_sub<4, 1>(one32, dd));     // 32 * 5 / rho + 1 = 3.1
+        u9_add(s.v, LM(l9_sub<4, 1>(l9_add(LM(b32, d32), LM(a32, c32)), y3), l9(wc.k32[1])).v);   // s below 81.5
+        w_finish(s, ld(q.sel[Q_VAR] + i), wc.ch32, sum, i, first);
+    }
 }
 
 __global__ void __launch_bounds__(256) quotient_limb_kernel(QuotientArgs q) {
@@ -419,10 +534,19 @@ void PolyEngine::quotient(const QuotientArgs &args) {
     q.gamma_x32 = mul_small<32>(args.gamma);
     q.widget_sum = nullptr;
     if (args.widgets) {
-        q.sep_k[0] = sep_powers<InlineMul>(args.range_ch);
-        q.sep_k[1] = sep_powers<InlineMul>(args.logic_ch);
-        q.sep_k[2] = sep_powers<InlineMul>(args.fixed_ch);
-        q.sep_k[3] = sep_powers<InlineMul>(args.var_ch);
+        const Fr ch[4] = {args.range_ch, args.logic_ch, args.fixed_ch, args.var_ch};
+        for (int w = 0; w < 4; w++) {
+            const SepPowers k = sep_powers<InlineMul>(ch[w]);
+            const Fr kj[4] = {k.k1, k.k2, k.k3, k.k4};
+            for (int j = 0; j < 4; j++) q.wc[w].k32[j] = mul_small<32>(kj[j]);
+            q.wc[w].k1024 = mul_small<1024>(k.k1);
+            q.wc[w].ch32 = mul_small<32>(ch[w]);
+        }
+        q.one32 = mul_small<32>(Fr::one());
+        q.two32 = mul_small<64>(Fr::one());
+        q.c81_32 = mul_small<32 * 81>(Fr::one());
+        q.c83_32 = mul_small<32 * 83>(Fr::one());
+        q.edwards_d32 = mul_small<32>(edwards_d<InlineMul>());
     }
     if (args.widgets) widget_sum_.reserve((size_t)args.n8 * sizeof(Fr));   // before the timed region: may allocate
     ZK_HIP(hipEventRecord(q_ev_[0], stream_));

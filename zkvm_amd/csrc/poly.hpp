@@ -26,7 +26,14 @@ struct QuotientArgs {
     // (first + world * k) mod 8.  One GPU: rot = 8, world = 1, first = 0.
     uint32_t rot, world, first;
     uint32_t widgets;                  // bit 0 range, 1 logic, 2 fixed-base, 3 curve-addition: selector is non-zero
-    SepPowers sep_k[4];                // powers of the four separation challenges squared (filled in by PolyEngine::quotient)
+    // Constants of the widget kernels, filled in by PolyEngine::quotient.  Those kernels carry every value x as 32 x
+    // (so that a limb product of two of them is again 32 times the Montgomery product), hence the factors 32:
+    struct WidgetConsts {
+        Fr k32[4];                     // 32 kappa^j, j = 1..4, kappa = the widget's separation challenge squared
+        Fr k1024;                      // 1024 kappa: takes a value that is not scaled into a scaled product with kappa
+        Fr ch32;                       // 32 times the separation challenge itself
+    } wc[4];                           // range, logic, fixed-base, curve addition
+    Fr one32, two32, c81_32, c83_32, edwards_d32;   // 32 * {1, 2, 81, 83, the curve's d}
     const Fr *widget_sum;              // sum of the active widgets' terms per point (filled in by PolyEngine::quotient), or null
 };
 

@@ -245,13 +245,46 @@ def test_gpu_proof_with_curve_widgets(orc):
         ctx.close()
 
 
+def _violate_one_widget(circ, w):
+    """A witness that breaks gates of widget w and nothing else: a variable all of whose cells lie in rows without an
+    arithmetic gate and without another widget's selector (in the row and in the row before it, which reads it as its
+    next row), changed in every one of its cells: every copy constraint and every arithmetic gate still hold."""
+    n = circ["n"]
+    sel = circ["selectors"]
+    sigma = circ["sigma_map"].reshape(-1)                      # cell col * n + row -> the next cell of its cycle
+    arith = sel[6].any(axis=1)
+    other = np.zeros(n, dtype=bool)
+    for k in range(4):
+        if k != w:
+            other |= sel[7 + k].any(axis=1)
+    own = np.nonzero(sel[7 + w].any(axis=1))[0]
+    for row in np.unique(np.concatenate([own, (own + 1) % n])):
+        for col in range(4):
+            cells = [col * n + int(row)]
+            while int(sigma[cells[-1]]) != cells[0]:
+                cells.append(int(sigma[cells[-1]]))
+            rows = [c % n for c in cells]
+            if any(arith[r] or other[r] or other[r - 1] for r in rows):
+                continue
+            bad = circ["wires"].copy()
+            value = M.fr_from_mont(bad[col, row])
+            for c in cells:
+                bad[c // n, c % n] = M.fr_to_mont((value + 1) % R)
+            flat = bad.reshape(4 * n, 4)
+            assert np.array_equal(flat, flat[sigma])           # the copy constraints hold
+            return bad
+    raise AssertionError("no variable of widget %d stands alone" % w)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("subset", [(0, 1, 2, 3), (0,), (1,), (2,), (3,), (1, 3)])
 def test_gpu_proof_with_every_widget_in_one_key(orc, subset):
     """circuits.widget_circuit: range, logic, fixed-base and curve-addition gates in one key of 2^12 rows (one launch per
     widget whose selector is not identically zero, summed per point, then the arithmetic and permutation terms); for
     the subsets the other widgets' selector rows are zeroed, which leaves their gates unconstrained but satisfied.
-    Proof = the oracle's, accepted by the verifier, and a violated range gate ends in the oracle's error."""
+    Proof = the oracle's over the 4n coset and, forced, over the reference's 8n coset; accepted by the verifier; a
+    violated range gate ends in the oracle's error; so does a witness that violates gates of one widget only (every
+    arithmetic gate and copy constraint intact: only the row-wise widget check can send it to the 8n coset)."""
     import plonk_check
     import zkvm_amd
     from zkvm_amd import api, circuits
@@ -267,7 +300,7 @@ def test_gpu_proof_with_every_widget_in_one_key(orc, subset):
         bl = circuits.random_blinders(11)
         want = op.prove(circ["wires"], circ["public_inputs"], bl)
         got = gp.prove(circ["wires"].reshape(-1, 4), circ["public_inputs"], bl)
-        assert want["rc"] == 0 and got["coset"] == 8
+        assert want["rc"] == 0 and got["coset"] == 4
         for key in ("challenges", "evals", "comms_inf", "comms"):
             assert np.array_equal(got[key], want[key]), key
         if subset == (0, 1, 2, 3):
@@ -283,5 +316,22 @@ def test_gpu_proof_with_every_widget_in_one_key(orc, subset):
             assert op.prove(bad, circ["public_inputs"], bl)["rc"] == 2
             with pytest.raises(api.PolynomialDegreeTooLarge):
                 gp.prove(bad.reshape(-1, 4), circ["public_inputs"], bl)
+        for w in subset:
+            bad = _violate_one_widget(circ, w)
+            assert op.prove(bad, circ["public_inputs"], bl)["rc"] == 2, w
+            with pytest.raises(api.PolynomialDegreeTooLarge):
+                gp.prove(bad.reshape(-1, 4), circ["public_inputs"], bl)
+            assert ctx._lib.zkgpu_prover_last_proof_coset(ctx._h) in (0, 8)
+        again = gp.prove(circ["wires"].reshape(-1, 4), circ["public_inputs"], bl)     # and the key still proves over 4n
+        assert again["coset"] == 4 and np.array_equal(again["comms"], want["comms"])
+        ctx.force_full_coset(True)
+        try:
+            gp8 = api.Prover(ctx, circ["n"], circ["constraints"], circ["selectors"].reshape(-1, 4), b"all-widgets", circ["pi_indexes"])
+            got8 = gp8.prove(circ["wires"].reshape(-1, 4), circ["public_inputs"], bl)
+            assert got8["coset"] == 8
+            for key in ("challenges", "evals", "comms_inf", "comms"):
+                assert np.array_equal(got8[key], want[key]), key
+        finally:
+            ctx.force_full_coset(False)
     finally:
         ctx.close()

@@ -230,6 +230,58 @@ void PolyEngine::gate_check(const Fr *wires, const Fr *sel_h, const Fr *pi, uint
     ZK_HIP(hipGetLastError());
 }
 
+// ---- widget gates, row by row -----------------------------------------------------------------------------------
+// For every row whose range, logic, fixed-base or curve-addition selector is not zero: does each part of that widget's
+// identity vanish on the witness?  (The prover weights the parts with powers of a challenge; all of them zero is what
+// makes the weighted sum zero whatever the challenge.)  sel_h: the selector values on the domain in the order of Sel,
+// Q_M ... Q_VAR.  The next row of the last row is the first (the domain is cyclic).
+static __device__ __noinline__ Fr fr_mul_outlined(Fr a, Fr b) { return Fr::mul(a, b); }
+struct OutlinedMul {
+    __device__ __forceinline__ static Fr mul(const Fr &a, const Fr &b) { return fr_mul_outlined(a, b); }
+};
+__global__ void __launch_bounds__(256) widget_check_kernel(const Fr *wires, const Fr *sel_h, uint32_t n, uint32_t widgets, uint32_t *flag) {
+    typedef FrRing<OutlinedMul> R;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = n;
+    bool on[4];
+    bool any = false;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        on[w] = ((widgets >> w) & 1u) && !ld(sel_h + (Q_RANGE + w) * N + i).is_zero();
+        any = any || on[w];
+    }
+    if (!any) return;
+    const uint32_t iw = (i + 1) & (n - 1);
+    const Fr a = ld(wires + i), b = ld(wires + N + i), c = ld(wires + 2 * N + i), d = ld(wires + 3 * N + i);
+    const Fr a_w = ld(wires + iw), b_w = ld(wires + N + iw), d_w = ld(wires + 3 * N + iw);
+    Fr p[5];
+    bool bad = false;
+    if (on[0]) {
+        w_range_parts<R>(a, b, c, d, d_w, p);
+        for (int j = 0; j < W_RANGE_PARTS; j++) bad = bad || !p[j].is_zero();
+    }
+    if (on[1]) {
+        w_logic_parts<R>(a, a_w, b, b_w, c, d, d_w, ld(sel_h + Q_C * N + i), p);
+        for (int j = 0; j < W_LOGIC_PARTS; j++) bad = bad || !p[j].is_zero();
+    }
+    if (on[2]) {
+        w_fixed_base_parts<R>(a, a_w, b, b_w, c, d, d_w, ld(sel_h + Q_L * N + i), ld(sel_h + Q_R * N + i), ld(sel_h + Q_C * N + i), p);
+        for (int j = 0; j < W_FIXED_PARTS; j++) bad = bad || !p[j].is_zero();
+    }
+    if (on[3]) {
+        w_curve_add_parts<R>(a, a_w, b, b_w, c, d, d_w, p);
+        for (int j = 0; j < W_CURVE_PARTS; j++) bad = bad || !p[j].is_zero();
+    }
+    if (bad) *flag = 1u;   // every writer stores the same value
+}
+void PolyEngine::widget_check(const Fr *wires, const Fr *sel_h, uint32_t n, uint32_t widgets, uint32_t *flag_dev) {
+    if (!n || !widgets) return;
+    ZK_REQUIRE((n & (n - 1)) == 0, ZKGPU_ERR_INVALID_ARG, "widget_check: n must be a power of two");
+    hipLaunchKernelGGL(widget_check_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream_, wires, sel_h, n, widgets, flag_dev);
+    ZK_HIP(hipGetLastError());
+}
+
 struct WindowArgs {
     const Fr *src[8];
     uint64_t first[8];
@@ -546,7 +598,7 @@ void PolyEngine::quotient(const QuotientArgs &args) {
         q.two32 = mul_small<64>(Fr::one());
         q.c81_32 = mul_small<32 * 81>(Fr::one());
         q.c83_32 = mul_small<32 * 83>(Fr::one());
-        q.edwards_d32 = mul_small<32>(edwards_d<InlineMul>());
+        q.edwards_d32 = mul_small<32>(edwards_d());
     }
     if (args.widgets) widget_sum_.reserve((size_t)args.n8 * sizeof(Fr));   // before the timed region: may allocate
     ZK_HIP(hipEventRecord(q_ev_[0], stream_));

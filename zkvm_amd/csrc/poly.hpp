@@ -74,6 +74,10 @@ class PolyEngine {
     // zero in some row.  wires = 4 x n values, sel_h = the 7 x n values of q_m q_l q_r q_o q_4 q_c q_arith, pi = n dense
     // public inputs.  The caller clears the flag.
     void gate_check(const Fr *wires, const Fr *sel_h, const Fr *pi, uint32_t n, uint32_t *flag_dev);
+    // The same for the widget gates (`widgets`: bit 0 range, 1 logic, 2 fixed-base, 3 curve addition): *flag_dev is set
+    // to 1 when, in a row whose selector of such a widget is not zero, some part of that widget's identity differs from
+    // zero.  sel_h = the 11 x n values of q_m ... q_variable_group_add in the order of Sel.
+    void widget_check(const Fr *wires, const Fr *sel_h, uint32_t n, uint32_t widgets, uint32_t *flag_dev);
     // dst[j * count + i] = src[j][first[j] + i] for j < m <= 8, i < count <= 8: a few coefficients of several vectors
     // gathered for one copy to the host
     void gather_windows(uint32_t m, const Fr *const *src, const uint64_t *first, uint32_t count, Fr *dst);

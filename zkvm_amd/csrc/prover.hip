@@ -154,6 +154,8 @@ void Prover::share_key(const Prover &src) {
     proved_once_ = false;
     for (int k = 0; k < 4; k++)
         for (int j = 0; j < 7; j++) sigma_top_[k][j] = src.sigma_top_[k][j];
+    for (int k = 0; k < N_SEL_TOPS; k++)
+        for (int j = 0; j < 7; j++) sel_top_[k][j] = src.sel_top_[k][j];
     pi_lagrange_idx_ = src.pi_lagrange_idx_;
     n_ = src.n_;
 }
@@ -367,11 +369,12 @@ void Prover::build_vanishing() {
     }
 }
 
-// Which coset the loaded key's proofs evaluate the quotient on.  With the arithmetic and permutation terms only, the
-// numerator has degree at most 5n + 6 and the quotient 4n + 6: its 4n evaluations over g<w_4n> fix it up to its seven
-// top coefficients, and those follow from the top coefficients of the round polynomials (quotient_half_coset).
+// Which coset the loaded key's proofs evaluate the quotient on.  The numerator has degree at most 5n + 6 (the
+// permutation term: z of degree n + 2 times four factors of degree n + 1; a widget's term is a selector times at most
+// four wire factors, 5n + 3) and the quotient 4n + 6: its 4n evaluations over g<w_4n> fix it up to its seven top
+// coefficients, and those follow from the top coefficients of the round and key polynomials (quotient_half_coset).
 void Prover::choose_coset() {
-    half_coset_ = !force_full_ && widgets_ == 0 && !shared() && n_ >= 16;
+    half_coset_ = !force_full_ && !shared() && n_ >= 16;
     last_half_ = false;
     if (!half_coset_) {
         evals4_.release();
@@ -389,6 +392,15 @@ void Prover::read_sigma_tops() {
     for (int k = 0; k < 4; k++) {
         sigma_top_[k][0] = sigma_top_[k][1] = Fr::zero();
         for (int j = 2; j < 7; j++) sigma_top_[k][j] = buf[k][4 - (j - 2)];   // coefficient n+1-j = buf index (n+1-j) - (n-5)
+    }
+    // coefficients n-1-j, j < 7, of the selector polynomials the widget terms multiply
+    if (widgets_) {
+        Fr sb[N_SEL_TOPS][7];
+        for (int k = 0; k < N_SEL_TOPS; k++)
+            ZK_HIP(hipMemcpyAsync(sb[k], key_poly(SEL_TOPS[k]) + (n - 7), 7 * sizeof(Fr), hipMemcpyDeviceToHost, stream_));
+        ZK_HIP(hipStreamSynchronize(stream_));
+        for (int k = 0; k < N_SEL_TOPS; k++)
+            for (int j = 0; j < 7; j++) sel_top_[k][j] = sb[k][6 - j];
     }
 }
 
@@ -482,8 +494,10 @@ void Prover::load_key(uint32_t n, uint64_t constraints, const uint64_t *selector
     choose_coset();
     if (half_coset_) {
         // the selector values on the domain itself stay for the row-wise gate check of every proof
-        sel_h_.reserve((size_t)7 * n * sizeof(Fr));
-        ZK_HIP(hipMemcpyAsync(sel_h_.p, stage, (size_t)7 * n * sizeof(Fr), hipMemcpyDeviceToDevice, stream_));
+        // (a key with widget gates: also q_range q_logic q_fixed_group_add q_variable_group_add, the next four in Sel)
+        const size_t n_sel_h = widgets_ ? 11 : 7;
+        sel_h_.reserve(n_sel_h * n * sizeof(Fr));
+        ZK_HIP(hipMemcpyAsync(sel_h_.p, stage, n_sel_h * n * sizeof(Fr), hipMemcpyDeviceToDevice, stream_));
         evals4_.reserve((size_t)(N_SEL + 2) * 4 * n * sizeof(Fr));
         build_key_evals(true, evals4_.as<Fr>(), (size_t)4 * n, stage, true, true);
         read_sigma_tops();
@@ -710,8 +724,9 @@ void Prover::load_key_bytes(const uint8_t *b, size_t len, const uint64_t *pi_ind
         // the 4n coset is every second point of the 8n coset: the stored vectors' even entries
         evals4_.reserve((size_t)(N_SEL + 2) * 4 * n * sizeof(Fr));
         for (int k = 0; k < N_SEL + 2; k++) poly_.take_even(evals + (size_t)k * N8, (size_t)4 * n, evals4_.as<Fr>() + (size_t)k * 4 * n);
-        sel_h_.reserve((size_t)7 * n * sizeof(Fr));
-        for (int k = 0; k < 7; k++)
+        const int n_sel_h = widgets_ ? 11 : 7;
+        sel_h_.reserve((size_t)n_sel_h * n * sizeof(Fr));
+        for (int k = 0; k < n_sel_h; k++)
             ntt_.transform(NTT_FFT, polys + (size_t)k * n, poly_len_[k], sel_h_.as<Fr>() + (size_t)k * n, log_n);
         read_sigma_tops();
     }
@@ -930,15 +945,78 @@ static void series_mul7(Fr a[7], const Fr f[7]) {
     for (int m = 0; m < 7; m++) a[m] = out[m];
 }
 
-// build_quotient_polynomial (quotient_poly.rs:15-100) for a key with the arithmetic and permutation terms only, for round
+// The top seven coefficients of a polynomial of degree at most `deg`: c[j] belongs to X^(deg - j), and is zero where
+// deg - j is negative.  Sums and products of such series are exact in their own top seven coefficients, so running a
+// widget's identity (widgets.hpp) over the series of the wire and selector polynomials yields the top coefficients of
+// that widget's term in the numerator.
+struct Top7 {
+    Fr c[7];
+    int64_t deg;
+};
+struct TopRing {
+    typedef Top7 V;
+    static Top7 add(const Top7 &a, const Top7 &b) {
+        const Top7 &hi = a.deg >= b.deg ? a : b, &lo = a.deg >= b.deg ? b : a;
+        Top7 r = hi;
+        for (int64_t j = hi.deg - lo.deg; j < 7; j++) r.c[j] = Fr::add(r.c[j], lo.c[j - (hi.deg - lo.deg)]);
+        return r;
+    }
+    static Top7 neg(const Top7 &a) {
+        Top7 r = a;
+        for (int j = 0; j < 7; j++) r.c[j] = Fr::neg(a.c[j]);
+        return r;
+    }
+    static Top7 sub(const Top7 &a, const Top7 &b) { return add(a, neg(b)); }
+    static Top7 mul(const Top7 &a, const Top7 &b) {
+        Top7 r;
+        r.deg = a.deg + b.deg;
+        for (int m = 0; m < 7; m++) {
+            Fr acc = Fr::zero();
+            for (int j = 0; j <= m; j++) acc = Fr::add(acc, Fr::mul(a.c[j], b.c[m - j]));
+            r.c[m] = acc;
+        }
+        return r;
+    }
+    static Top7 scale(const Top7 &a, const Fr &k) {
+        Top7 r = a;
+        for (int j = 0; j < 7; j++) r.c[j] = Fr::mul(a.c[j], k);
+        return r;
+    }
+    template <uint32_t K>
+    static Top7 small(const Top7 &a) {
+        Top7 r = a;
+        for (int j = 0; j < 7; j++) r.c[j] = mul_small<K>(a.c[j]);
+        return r;
+    }
+    static Top7 cst(uint32_t k) {
+        Top7 r;
+        r.deg = 0;
+        r.c[0] = k == 1 ? Fr::one() : Fr::from_u32(k);
+        for (int j = 1; j < 7; j++) r.c[j] = Fr::zero();
+        return r;
+    }
+};
+// the series of p(w X) from that of p: the coefficient of X^m gains w^m, and w^n = 1
+static Top7 top_next_row(const Top7 &p, const Domain &dn) {
+    Top7 r = p;
+    Fr pw = Fr::pow_u64(dn.group_gen, (uint64_t)(p.deg % (int64_t)dn.size));
+    for (int j = 0; j < 7; j++) {
+        r.c[j] = Fr::mul(p.c[j], pw);
+        pw = Fr::mul(pw, dn.group_gen_inv);
+    }
+    return r;
+}
+
+// build_quotient_polynomial (quotient_poly.rs:15-100) for round
 // polynomials of the lengths prove() produces (wires n + 2, z n + 3) whose numerator is known to vanish on the domain.
 // The numerator N has degree at most 5n + 6, so t = N / Z_H has at most 4n + 7 coefficients.  The pointwise identity is
 // evaluated on the 4n points g w_4n^k -- every second point of the reference's 8n coset, so the same kernel runs with
 // the slice parameters (first 0, step 2) and the "next row" four places on -- and the inverse coset transform returns
 // t modulo X^4n - g^4n, i.e. r_i = t_i + g^4n t_(4n+i) for i < 7 and t_i elsewhere.  The seven top coefficients are
 // those of N, t_(4n+i) = N_(5n+i), and only alpha (z prod_w (w + beta k_w X + gamma) - z(wX) prod_w (w + beta sigma_w +
-// gamma)) reaches those degrees: they are products of the seven top coefficients of each factor, which the host holds
-// in tops_host_ (wires: coefficients n-5 .. n+1, z: n-4 .. n+2, gathered right after blinding).  Every value equals the
+// gamma)) and the widget terms (a selector times at most four wire factors: degree 5n + 3) reach those degrees: they are
+// products of the seven top coefficients of each factor, which the host holds in tops_host_ (wires: coefficients
+// n-5 .. n+1, z: n-4 .. n+2, gathered right after blinding), sigma_top_ and sel_top_.  Every value equals the
 // reference's: both are the coefficients of the one polynomial t.
 uint64_t Prover::quotient_half_coset(const Fr *z, const Fr *const wires[4], const Fr ch[7], const Fr *pi_values, const Fr *pi_poly,
                                      Fr *t_out) {
@@ -990,7 +1068,7 @@ uint64_t Prover::quotient_half_coset(const Fr *z, const Fr *const wires[4], cons
     q.world = 2;
     q.first = 0;
     q.rot = 4;
-    q.widgets = 0;
+    q.widgets = widgets_;
     poly_.quotient(q);
     ntt_.transform(NTT_COSET_IFFT, t_out, L, t_out, log_n_ + 2);
 
@@ -1015,13 +1093,60 @@ uint64_t Prover::quotient_half_coset(const Fr *z, const Fr *const wires[4], cons
         for (int j = 0; j < 7; j++) f[j] = Fr::add(f[j], Fr::mul(beta, sigma_top_[k][j]));
         series_mul7(cp, f);
     }
+    // numerator coefficients 5n+6-j, j < 7
+    Fr ntop[7];
+    for (int j = 0; j < 7; j++) ntop[j] = Fr::mul(alpha, Fr::sub(id[j], cp[j]));
+    if (widgets_) {
+        typedef TopRing R;
+        Top7 w[4], sel[N_SEL_TOPS];
+        for (int k = 0; k < 4; k++) {
+            w[k].deg = (int64_t)n + 1;
+            for (int j = 0; j < 7; j++) w[k].c[j] = win[7 * k + 6 - j];
+        }
+        for (int k = 0; k < N_SEL_TOPS; k++) {
+            sel[k].deg = (int64_t)n - 1;
+            for (int j = 0; j < 7; j++) sel[k].c[j] = sel_top_[k][j];
+        }
+        const Top7 &a = w[0], &b = w[1], &c = w[2], &d = w[3];
+        const Top7 a_w = top_next_row(a, dn), b_w = top_next_row(b, dn), d_w = top_next_row(d, dn);
+        const Top7 &q_l = sel[4], &q_r = sel[5], &q_c = sel[6];   // SEL_TOPS: range logic fixed var q_l q_r q_c
+        Top7 p[5], term[4];
+        bool have[4] = {false, false, false, false};
+        if (widgets_ & 1u) {
+            w_range_parts<R>(a, b, c, d, d_w, p);
+            term[0] = w_combine<R>(p, W_RANGE_PARTS, sep_powers<InlineMul>(ch[3]));
+            have[0] = true;
+        }
+        if (widgets_ & 2u) {
+            w_logic_parts<R>(a, a_w, b, b_w, c, d, d_w, q_c, p);
+            term[1] = w_combine<R>(p, W_LOGIC_PARTS, sep_powers<InlineMul>(ch[4]));
+            have[1] = true;
+        }
+        if (widgets_ & 4u) {
+            w_fixed_base_parts<R>(a, a_w, b, b_w, c, d, d_w, q_l, q_r, q_c, p);
+            term[2] = w_combine<R>(p, W_FIXED_PARTS, sep_powers<InlineMul>(ch[5]));
+            have[2] = true;
+        }
+        if (widgets_ & 8u) {
+            w_curve_add_parts<R>(a, a_w, b, b_w, c, d, d_w, p);
+            term[3] = w_combine<R>(p, W_CURVE_PARTS, sep_powers<InlineMul>(ch[6]));
+            have[3] = true;
+        }
+        for (int k = 0; k < 4; k++) {
+            if (!have[k]) continue;
+            const Top7 t = R::scale(R::mul(term[k], sel[k]), ch[3 + k]);   // widget `compute_quotient_i`
+            const int64_t shift = (int64_t)(5 * n + 6) - t.deg;
+            ZK_REQUIRE(shift >= 0, ZKGPU_ERR_INTERNAL, "a widget term above the numerator's degree bound");
+            for (int64_t j = shift; j < 7; j++) ntop[j] = Fr::add(ntop[j], t.c[j - shift]);
+        }
+    }
     const Domain d8 = Domain::make(8 * n);
     const Fr g4n = Fr::pow_u64(Fr::inv(d8.generator_inv), L);
     uint64_t idx[7];
     Fr hi[7], lo[7];
     bool sub[7], set[7];
     for (int i = 0; i < 7; i++) {
-        hi[i] = Fr::mul(alpha, Fr::sub(id[6 - i], cp[6 - i]));   // t_(4n+i) = N_(5n+i): entry j = 6 - i
+        hi[i] = ntop[6 - i];   // t_(4n+i) = N_(5n+i): entry j = 6 - i
         lo[i] = Fr::mul(g4n, hi[i]);
         idx[i] = (uint64_t)i;
         sub[i] = true;
@@ -1279,6 +1404,7 @@ int Prover::prove(const uint64_t *wires_host, const uint64_t *public_inputs_host
         Fr *td = tops_dev_.as<Fr>();
         ZK_HIP(hipMemsetAsync(td + FLAG_AT, 0, sizeof(Fr), stream_));
         poly_.gate_check(wires, sel_h_.as<Fr>(), p_pi, (uint32_t)n, reinterpret_cast<uint32_t *>(td + FLAG_AT));
+        poly_.widget_check(wires, sel_h_.as<Fr>(), (uint32_t)n, widgets_, reinterpret_cast<uint32_t *>(td + FLAG_AT));
         const Fr *src[4] = {p_a, p_b, p_c, p_d};
         const uint64_t first[4] = {n - 5, n - 5, n - 5, n - 5};
         poly_.gather_windows(4, src, first, 7, td);

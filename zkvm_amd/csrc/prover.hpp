@@ -199,10 +199,15 @@ class Prover {
     bool half_coset_ = false, last_half_ = false, force_full_ = false, proved_once_ = false;
     bool evals8_built_ = false;   // evals_ holds the 8n vectors (always true for keys that do not use the 4n coset)
     DevBuf evals4_;               // (N_SEL + 2) x 4n: the key's vectors over the 4n coset
-    DevBuf sel_h_;                // 7 x n: q_m q_l q_r q_o q_4 q_c q_arith on the domain itself (the row-wise gate check)
+    DevBuf sel_h_;                // 7 x n: q_m q_l q_r q_o q_4 q_c q_arith on the domain itself (the row-wise gate check);
+                                  // 11 x n with the four widget selectors for a key that has widget gates
     DevBuf tops_dev_;             // gathered top coefficients + the gate check's flag, copied to tops_host_ in one piece
     Fr *tops_host_ = nullptr;     // pinned: 5 windows of 7 coefficients, then the flag word
     Fr sigma_top_[4][7];          // coefficients n+1-j (j < 7) of the four sigma polynomials
+    // coefficients n-1-j (j < 7) of the selector polynomials that widget terms multiply (keys with widget gates)
+    static const int N_SEL_TOPS = 7;
+    static constexpr int SEL_TOPS[N_SEL_TOPS] = {Q_RANGE, Q_LOGIC, Q_FIXED, Q_VAR, Q_L, Q_R, Q_C};
+    Fr sel_top_[N_SEL_TOPS][7];
     DevBuf pi_lagrange_;                  // for keys with few public inputs: L_j on the coset the key proves over, one vector per position
     std::vector<uint64_t> pi_lagrange_idx_;   // the distinct positions, ascending; empty = not resident
 };

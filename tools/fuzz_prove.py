@@ -1,5 +1,6 @@
 """Randomised differential check of the whole prover: circuits built from random sequences of Composer operations
-(arithmetic gates, booleans, selects, range and logic components, curve additions, public inputs), proved on the
+(arithmetic gates, booleans, selects, range and logic components, fixed-base multiplications, curve additions, public
+inputs), proved on the
 GPU and by the CPU oracle with the same blinders; every commitment, evaluation and challenge must agree.  One circuit
 in seven gets a corrupted witness value or public input: both sides must then agree on success or failure as well
 (the GPU decides there between its 4n-coset and 8n-coset quotient).
@@ -50,6 +51,8 @@ def random_circuit(rng):
         elif use_widgets:
             if len(points) < 2:
                 points.append(c.append_point(C.jubjub_mul(C.JUBJUB_GENERATOR, int(rng.integers(1, 1 << 40)))))
+            elif len(points) == 2 and rng.random() < 0.5:
+                points.append(c.component_mul_generator(c.append_witness(int(rng.integers(1, 1 << 62)))))
             else:
                 points.append(c.component_add_point(points[int(rng.integers(0, len(points)))], points[-1]))
     return c.tables()
@@ -64,7 +67,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.Generator(np.random.PCG64(seed))
     tau = M.random_fr_mont(1, seed=seed + 1000)[0]
-    srs, _ = orc.srs_powers(orc.g1_generator(), tau, 1024 + 7)
+    srs, _ = orc.srs_powers(orc.g1_generator(), tau, 2048 + 7)
     ctx = zkvm_amd.Context(0)
     routes = {0: 0, 4: 0, 8: 0}
     corrupted = 0
@@ -73,7 +76,19 @@ def main():
         n = circ["n"]
         if rng.random() < 1 / 7:
             corrupted += 1
-            if rng.random() < 0.8 or not len(circ["public_inputs"]):
+            u = rng.random()
+            if u < 0.4:
+                # one variable changed in every cell of its copy cycle: the copy constraints still hold, only gates break
+                # (in a widget row: only the row-wise widget check tells the GPU to leave the 4n coset)
+                circ["wires"] = circ["wires"].copy()
+                sigma = circ["sigma_map"].reshape(-1)
+                cells = [int(rng.integers(0, 4)) * n + int(rng.integers(0, circ["constraints"]))]
+                while int(sigma[cells[-1]]) != cells[0]:
+                    cells.append(int(sigma[cells[-1]]))
+                value = (M.fr_from_mont(circ["wires"][cells[0] // n, cells[0] % n]) + 1 + int(rng.integers(0, 7))) % M.R_MOD
+                for cell in cells:
+                    circ["wires"][cell // n, cell % n] = M.fr_to_mont(value)
+            elif u < 0.85 or not len(circ["public_inputs"]):
                 circ["wires"] = circ["wires"].copy()
                 circ["wires"][int(rng.integers(0, 4)), int(rng.integers(0, circ["constraints"])), 0] ^= np.uint64(1 << int(rng.integers(0, 60)))
             else:

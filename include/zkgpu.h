@@ -265,12 +265,13 @@ int zkgpu_prover_key_eval8n(zkgpu_ctx *ctx, int which, uint64_t *out);
 /* Elements zkgpu_prover_key_eval8n writes: 8n, or 8n / world for a shared key; 0 when no key is loaded. */
 size_t zkgpu_prover_key_eval_len(const zkgpu_ctx *ctx);
 /* Which coset zkgpu_prove evaluates the quotient's numerator on.  The reference always takes the 8n-point coset
- * (plonk/src/proof_system/quotient_poly.rs:28,46-51).  For a key whose range, logic and curve selectors are identically
- * zero the quotient has at most 4n + 7 coefficients, and this library evaluates on the 4n points g w_4n^k (every second
- * point of the 8n coset) and restores the seven top coefficients from those of the round polynomials: the same
- * coefficients at half the transform and pointwise work.  A proof whose witness violates a gate or the permutation
- * (the numerator then does not vanish on the domain) is detected beforehand and runs over the 8n coset, so it ends in
- * the reference's error.  zkgpu_prover_force_full_coset(ctx, 1) makes keys loaded afterwards use the 8n coset always;
+ * (plonk/src/proof_system/quotient_poly.rs:28,46-51).  The quotient has at most 4n + 7 coefficients (the numerator's
+ * permutation term reaches degree 5n + 6, a widget's term 5n + 3), and from n = 16 up this library evaluates on the 4n
+ * points g w_4n^k (every second point of the 8n coset) and restores the seven top coefficients from those of the round
+ * and key polynomials: the same coefficients at half the transform and pointwise work.  A proof whose witness violates
+ * a gate (arithmetic or widget) or the permutation (the numerator then does not vanish on the domain) is detected
+ * beforehand and runs over the 8n coset, so it ends in the reference's error; so does every proof of a key loaded
+ * under zkgpu_set_collective.  zkgpu_prover_force_full_coset(ctx, 1) makes keys loaded afterwards use the 8n coset always;
  * zkgpu_prover_last_proof_coset returns 4 or 8 for the most recent zkgpu_prove on this context (0 before the first).
  * No counterpart in the reference. */
 int zkgpu_prover_force_full_coset(zkgpu_ctx *ctx, int on);

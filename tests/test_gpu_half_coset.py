@@ -1,6 +1,6 @@
 """The quotient over the 4n coset.  The reference evaluates the quotient's numerator on 8n points
-(plonk/src/proof_system/quotient_poly.rs:28,46-51); for keys with the arithmetic and permutation terms only the library
-takes every second one of them and restores the seven top coefficients.  Proofs must equal the oracle's (which follows
+(plonk/src/proof_system/quotient_poly.rs:28,46-51); the library takes every second one of them and restores the seven
+top coefficients (keys with widget gates: tests/test_composer.py).  Proofs must equal the oracle's (which follows
 the reference over 8n points) bit for bit on either route, and a witness that violates a gate or a copy constraint must
 end in the reference's error."""
 import numpy as np

@@ -1,11 +1,13 @@
 """The algebra behind the prover's quotient over 4n points, checked on the CPU against the oracle's quotient (which
 follows the reference over the 8n coset, plonk/src/proof_system/quotient_poly.rs:15-100).
 
-For a key with the arithmetic and permutation terms only the quotient t has at most 4n + 7 coefficients.  The library
+The quotient t has at most 4n + 7 coefficients (the permutation term of the numerator reaches degree 5n + 6, a widget's
+term 5n + 3, the rest less).  The library
 (zkvm_amd/csrc/prover.hip: quotient_half_coset) evaluates the numerator on the 4n points g w_4n^k, which fixes t modulo
 X^4n - g^4n, and takes the seven top coefficients from the top coefficients of the round polynomials:
     t_(4n+i) = [alpha (z prod_w (w + beta k_w X + gamma) - z(wX) prod_w (w + beta sigma_w + gamma))]_(5n+i),  i < 7.
-Both statements are verified here with Python integers on the oracle's own t."""
+(a key with widget gates adds the top coefficients of its widget terms, which the GPU tests compare through whole
+proofs).  Both statements are verified here with Python integers on the oracle's own t."""
 import numpy as np
 import pytest
 
@@ -87,3 +89,41 @@ def test_top_coefficients_and_folding(orc, log_n, seed):
     r = _ints(orc.fft("coset_ifft", ev_f, 4 * n))
     rebuilt = [(r[i] - (g4n * t[4 * n + i] if i < 7 else 0)) % R for i in range(4 * n)] + t[4 * n:]
     assert rebuilt == t
+
+
+@pytest.mark.parametrize("which", ["range_logic", "curve"])
+def test_quotient_of_a_widget_key_has_4n_plus_7_coefficients(orc, which):
+    """The degree bound that lets keys with widget gates take the 4n route too: the oracle's quotient (over 8n points)
+    of a satisfied circuit with range and logic gates, and of one with fixed-base and curve-addition gates."""
+    import test_composer as T
+    c = (T.widget_circuit(0xbeef, 0x1234, 16) if which == "range_logic" else T.curve_circuit()).tables()
+    n = c["n"]
+    c["selectors"][11:15] = np.stack([orc.sigma_to_lagrange(c["sigma_map"][k]) for k in range(4)])
+    assert any(c["selectors"][7 + w].any() for w in range(4))
+    srs, _ = orc.g1_multiples_of_generator(1, n + 7)
+    op = orc.Prover(n, c["constraints"], c["selectors"], srs, b"algebra", c["pi_indexes"], threads=4)
+    assert op.preprocess_rc == 0
+    ch = M.random_fr_mont(7, seed=77)
+    bl = M.random_fr_mont(11, seed=78)
+    polys = []
+    for k in range(4):
+        v = _ints(orc.fft("ifft", c["wires"][k])) + [0, 0]
+        b = _ints(bl[2 * k:2 * k + 2])
+        for i in range(2):
+            v[i] = (v[i] - b[i]) % R
+            v[n + i] = b[i]
+        polys.append(M.fr_vec_to_mont(v))
+    zvec = orc.permutation_vec(c["wires"], [op.poly(11 + k) for k in range(4)], ch[1], ch[2])
+    zv = _ints(orc.fft("ifft", zvec)) + [0, 0, 0]
+    b = _ints(bl[8:11])
+    for i in range(3):
+        zv[i] = (zv[i] - b[i]) % R
+        zv[n + i] = b[i]
+    dense_pi = np.zeros((n, 4), np.uint64)
+    for j, i in enumerate(c["pi_indexes"]):
+        dense_pi[i] = c["public_inputs"][j]
+    t = _ints(op.quotient(M.fr_vec_to_mont(zv), *polys, orc.fft("ifft", dense_pi), ch))
+    assert len(t) == 4 * n + 7
+    g4n = pow(7, 4 * n, R)
+    folded = [(t[i] + (g4n * t[4 * n + i] if i < 7 else 0)) % R for i in range(4 * n)]
+    assert np.array_equal(orc.fft("coset_fft", M.fr_vec_to_mont(t), 8 * n)[::2], orc.fft("coset_fft", M.fr_vec_to_mont(folded), 4 * n))

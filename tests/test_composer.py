@@ -324,6 +324,15 @@ def test_gpu_proof_with_every_widget_in_one_key(orc, subset):
             assert ctx._lib.zkgpu_prover_last_proof_coset(ctx._h) in (0, 8)
         again = gp.prove(circ["wires"].reshape(-1, 4), circ["public_inputs"], bl)     # and the key still proves over 4n
         assert again["coset"] == 4 and np.array_equal(again["comms"], want["comms"])
+        if subset in ((0, 1, 2, 3), (1, 3)):
+            # the reference's byte format (its 8n vectors are built for it on demand) and a key restored from it
+            blob = gp.to_bytes()
+            assert np.array_equal(blob, op.to_bytes())
+            restored = api.Prover.try_from_bytes(ctx, blob, circ["pi_indexes"]).prove(circ["wires"].reshape(-1, 4), circ["public_inputs"], bl)
+            assert restored["coset"] == 4
+            for key in ("challenges", "evals", "comms_inf", "comms"):
+                assert np.array_equal(restored[key], want[key]), key
+            ctx.srs_load(srs)                                                          # the blob carried its own commit key
         ctx.force_full_coset(True)
         try:
             gp8 = api.Prover(ctx, circ["n"], circ["constraints"], circ["selectors"].reshape(-1, 4), b"all-widgets", circ["pi_indexes"])

@@ -150,15 +150,31 @@ struct Fp_ {
         constexpr uint32_t MASK = (1u << UL) - 1u;
         uint32_t m[UN];
         uint64_t c = 0;
+        if constexpr (P::UINV == MASK) {
+            // The modulus is 1 modulo 2^UL: m = -c mod 2^UL, and c + m * 1 is c rounded up to a multiple of 2^UL.  With
+            // c' = c + (2^UL - 1) the carry is c' >> UL and m = ~c' mod 2^UL: one 64-bit addition of a constant in place
+            // of a negation, a 64-bit addition of m and their dependency.
 #pragma unroll
-        for (int k = 0; k < UN; k++) {
+            for (int k = 0; k < UN; k++) {
+                c += MASK;
 #pragma unroll
-            for (int i = 0; i <= k; i++) c += (uint64_t)x[i] * y[k - i];
+                for (int i = 0; i <= k; i++) c += (uint64_t)x[i] * y[k - i];
 #pragma unroll
-            for (int i = 0; i < k; i++) c += (uint64_t)m[i] * P::umod(k - i);
-            m[k] = ((uint32_t)c * P::UINV) & MASK;
-            c += (uint64_t)m[k] * P::umod(0);
-            c >>= UL;
+                for (int i = 0; i < k; i++) c += (uint64_t)m[i] * P::umod(k - i);
+                m[k] = ~(uint32_t)c & MASK;
+                c >>= UL;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < UN; k++) {
+#pragma unroll
+                for (int i = 0; i <= k; i++) c += (uint64_t)x[i] * y[k - i];
+#pragma unroll
+                for (int i = 0; i < k; i++) c += (uint64_t)m[i] * P::umod(k - i);
+                m[k] = ((uint32_t)c * P::UINV) & MASK;
+                c += (uint64_t)m[k] * P::umod(0);
+                c >>= UL;
+            }
         }
 #pragma unroll
         for (int k = UN; k < 2 * UN - 1; k++) {

@@ -553,11 +553,18 @@ def run_prove(args, rank, world, local, device):
         del sc
     value = (1 if sharded else world) * args.steps / elapsed
     if rank == 0 and not sharded and not args.no_sub_records:
-        out["with_h2d"] = prove_with_transfers(prover, circ, blinders, n, proof, 1e3 * elapsed / args.steps, max(args.steps // 2, 4))
-        out["proofs_in_flight"] = proofs_in_flight(prover, wires, circ, blinders, proof, max(args.steps // 2, 4), elapsed / args.steps)
+        # extras beside the headline: a failure in one of them is written into the line instead of losing it
+        def extra(name, make):
+            try:
+                out[name] = make()
+            except Exception as e:   # noqa: BLE001
+                out.setdefault("sub_record_error", {})[name] = "%s: %s" % (type(e).__name__, e)
+        extra("with_h2d", lambda: prove_with_transfers(prover, circ, blinders, n, proof, 1e3 * elapsed / args.steps, max(args.steps // 2, 4)))
+        extra("proofs_in_flight", lambda: proofs_in_flight(prover, wires, circ, blinders, proof, max(args.steps // 2, 4), elapsed / args.steps))
         if (args.circuit == "widgets" or not args.no_widget_record) and n >= (1 << 14):   # eight rounds of every widget: 2^12 rows
-            out["widgets"] = widget_key_record(ctx, n, device, max(args.steps // 3, 3))
-            out["rooflines"].append(out["widgets"].pop("roofline"))
+            extra("widgets", lambda: widget_key_record(ctx, n, device, max(args.steps // 3, 3)))
+            if "widgets" in out:
+                out["rooflines"].append(out["widgets"].pop("roofline"))
 
     # ---- the other parts of the metric, in the same run -----------------------------------------------------------
     if not args.no_sub_records and not sharded:
@@ -635,7 +642,7 @@ def run_prove(args, rank, world, local, device):
                 raise
             import traceback
             traceback.print_exc()
-            out["sub_record_error"] = "%s: %s" % (type(exc).__name__, exc)
+            out.setdefault("sub_record_error", {})["multi_gpu_records"] = "%s: %s" % (type(exc).__name__, exc)
     return value, elapsed, out, ctx
 
 

@@ -721,10 +721,6 @@ __global__ void __launch_bounds__(256) scan_finish_kernel(const uint32_t *counts
 // buckets are left out (they go through msm_big_*).  Two passes over the counts: class histogram, then placement.
 static const uint32_t N_CLASSES = BIG_BUCKET + 1;
 
-// A workgroup walks SCHED_ITEMS * 1024 buckets: one returning atomic per class and workgroup on the sum's class cursors
-// -- all workgroups meet on the same few addresses (most buckets of a large sum have nearly the same size), so their
-// number, not the LDS histogram, sets the pace.
-static const uint32_t SCHED_ITEMS = 8;
 template <int PASS>
 __global__ void __launch_bounds__(1024) msm_schedule_kernel(const uint32_t *counts, uint32_t nb, uint32_t shift,
                                                             uint32_t big, uint32_t *class_cursor, uint32_t *order,
@@ -737,19 +733,13 @@ __global__ void __launch_bounds__(1024) msm_schedule_kernel(const uint32_t *coun
     class_cursor += (size_t)sum * (N_CLASSES + 1);
     for (uint32_t t = threadIdx.x; t < N_CLASSES; t += blockDim.x) hist[t] = 0;
     __syncthreads();
-    const uint32_t i0 = blockIdx.x * (SCHED_ITEMS * 1024u) + threadIdx.x;
-    uint32_t cls[SCHED_ITEMS], rank[SCHED_ITEMS];
-#pragma unroll
-    for (uint32_t k = 0; k < SCHED_ITEMS; k++) {
-        const uint32_t i = i0 + k * 1024u;
-        cls[k] = 0xffffffffu;
-        rank[k] = 0;
-        if (i < nb) {
-            const uint32_t cnt = counts[i];
-            if (cnt <= big) {
-                cls[k] = BIG_BUCKET - (cnt >> shift);
-                rank[k] = atomicAdd(&hist[cls[k]], 1u);
-            }
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cls = 0xffffffffu, rank = 0;
+    if (i < nb) {
+        uint32_t cnt = counts[i];
+        if (cnt <= big) {
+            cls = BIG_BUCKET - (cnt >> shift);
+            rank = atomicAdd(&hist[cls], 1u);
         }
     }
     __syncthreads();
@@ -757,9 +747,7 @@ __global__ void __launch_bounds__(1024) msm_schedule_kernel(const uint32_t *coun
         if (hist[t]) base[t] = atomicAdd(&class_cursor[t], hist[t]);
     if (!PASS) return;
     __syncthreads();
-#pragma unroll
-    for (uint32_t k = 0; k < SCHED_ITEMS; k++)
-        if (cls[k] != 0xffffffffu) order[base[cls[k]] + rank[k]] = i0 + k * 1024u;
+    if (cls != 0xffffffffu) order[base[cls] + rank] = i;
 }
 // exclusive scan of the class histogram (in place), total scheduled buckets in class_cursor[N_CLASSES]
 __global__ void msm_schedule_scan_kernel(uint32_t *class_cursor, uint32_t first_sum) {
@@ -1699,10 +1687,10 @@ void MsmEngine::msm_batch_device(uint32_t m, const Fr *const *scalars_dev, const
             hipLaunchKernelGGL(msm_schedule_small_kernel, dim3(count), dim3(1024), 0, st, counts, B, class_shift, big,
                                class_cursor + (size_t)first * (N_CLASSES + 1), order + (size_t)first * B);
         } else {
-            hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, SCHED_ITEMS * 1024), count), dim3(1024), 0, st, counts_.as<uint32_t>(), B,
+            hipLaunchKernelGGL(msm_schedule_kernel<0>, dim3(ceil_div(B, 1024), count), dim3(1024), 0, st, counts_.as<uint32_t>(), B,
                                class_shift, big, class_cursor, order, first);
             hipLaunchKernelGGL(msm_schedule_scan_kernel, dim3(count), dim3(64), 0, st, class_cursor, first);
-            hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, SCHED_ITEMS * 1024), count), dim3(1024), 0, st, counts_.as<uint32_t>(), B,
+            hipLaunchKernelGGL(msm_schedule_kernel<1>, dim3(ceil_div(B, 1024), count), dim3(1024), 0, st, counts_.as<uint32_t>(), B,
                                class_shift, big, class_cursor, order, first);
         }
         mark_if(6);

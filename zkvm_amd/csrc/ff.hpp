@@ -327,8 +327,93 @@ struct Fp_ {
         }
         return res;
     }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // Host side: the inverse by the binary extended Euclidean algorithm on 64-bit words (u, v shrink by shifts and
+    // subtractions while x1 a = u and x2 a = v hold modulo p), about four times faster than the power a^(p-2) below.
+    // The host inverts once per commitment batch and per permutation, between two launches.  The argument is a R, its
+    // integer inverse a^-1 R^-1; two products by R^2 lead back to a^-1 R.  Zero maps to zero.
+    static inline Fp_ inv_words64(const Fp_ &a) {
+        constexpr int W = N / 2;
+        if (a.is_zero()) return a;
+        uint64_t u[W], v[W], x1[W], x2[W], p[W];
+        __builtin_memcpy(u, a.v, sizeof u);
+        for (int i = 0; i < W; i++) {
+            p[i] = P::mod(2 * i) | (uint64_t)P::mod(2 * i + 1) << 32;
+            v[i] = p[i];
+            x1[i] = x2[i] = 0;
+        }
+        x1[0] = 1;
+        auto is_one = [](const uint64_t *t) {
+            uint64_t o = t[0] ^ 1;
+            for (int i = 1; i < W; i++) o |= t[i];
+            return o == 0;
+        };
+        auto shr1 = [](uint64_t *t) {
+            for (int i = 0; i < W - 1; i++) t[i] = t[i] >> 1 | t[i + 1] << 63;
+            t[W - 1] >>= 1;
+        };
+        auto halve = [&](uint64_t *x) {   // x / 2 modulo p: x + p stays within the words (both moduli leave the top bit free)
+            if (x[0] & 1) {
+                unsigned __int128 c = 0;
+                for (int i = 0; i < W; i++) {
+                    c += (unsigned __int128)x[i] + p[i];
+                    x[i] = (uint64_t)c;
+                    c >>= 64;
+                }
+            }
+            shr1(x);
+        };
+        auto geq = [](const uint64_t *s, const uint64_t *t) {
+            for (int i = W - 1; i >= 0; i--)
+                if (s[i] != t[i]) return s[i] > t[i];
+            return true;
+        };
+        auto sub = [](uint64_t *s, const uint64_t *t) {   // s -= t, returns the borrow
+            uint64_t borrow = 0;
+            for (int i = 0; i < W; i++) {
+                const unsigned __int128 d = (unsigned __int128)s[i] - t[i] - borrow;
+                s[i] = (uint64_t)d;
+                borrow = (uint64_t)(d >> 64) & 1;
+            }
+            return borrow;
+        };
+        auto sub_mod = [&](uint64_t *s, const uint64_t *t) {   // s = s - t modulo p for s, t below p
+            if (sub(s, t)) {
+                unsigned __int128 c = 0;
+                for (int i = 0; i < W; i++) {
+                    c += (unsigned __int128)s[i] + p[i];
+                    s[i] = (uint64_t)c;
+                    c >>= 64;
+                }
+            }
+        };
+        while (!is_one(u) && !is_one(v)) {
+            while (!(u[0] & 1)) {
+                shr1(u);
+                halve(x1);
+            }
+            while (!(v[0] & 1)) {
+                shr1(v);
+                halve(x2);
+            }
+            if (geq(u, v)) {
+                sub(u, v);
+                sub_mod(x1, x2);
+            } else {
+                sub(v, u);
+                sub_mod(x2, x1);
+            }
+        }
+        Fp_ r;
+        __builtin_memcpy(r.v, is_one(u) ? x1 : x2, sizeof x1);
+        return mul(mul(r, r2()), r2());
+    }
+#endif
     // a^(p-2); zero maps to zero
     FF_HD static Fp_ inv(const Fp_ &a) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+        return inv_words64(a);
+#endif
         uint32_t e[N];
         uint64_t borrow = 2;
 #pragma unroll

@@ -1,6 +1,6 @@
 """GPU parity at the sizes the benchmark is quoted on, bit for bit against the CPU oracle on raw limbs: a 2^20-point
 commitment over a real tau-power SRS (uniform and witness-like scalars), the 2^23-point coset transforms of the quotient,
-one whole 2^20-gate proof, and - where the oracle would need minutes - the 2^24-point commitment through properties of
+one whole 2^20-gate proof, a 2^17-row proof of a key with every widget, and - where the oracle would need minutes - the 2^24-point commitment through properties of
 the group.  The oracle legs run for tens of seconds each (the reference's FFT is serial, its MSM window-parallel)."""
 import numpy as np
 import pytest
@@ -110,6 +110,35 @@ def test_prove_2_20_equals_oracle_proof(ctx, orc, srs20):
     wxy, winf = op.selector_comms()
     assert np.array_equal(sinf, winf) and np.array_equal(sxy, wxy)
     c["selectors"] = None
+    want = op.prove(c["wires"], c["public_inputs"], bl)
+    assert want["rc"] == 0
+    for key in ("challenges", "evals", "comms_inf", "comms"):
+        assert np.array_equal(got[key], want[key]), key
+
+
+@pytest.mark.timeout(900)
+def test_prove_2_17_rows_with_every_widget_equals_oracle_proof(orc, srs20):
+    """The same for a key in which every widget has gates (range, logic, fixed-base multiplication, curve addition:
+    widget/*/proverkey.rs), 2^17 rows: the proof over the 4n coset equals the oracle's, which follows the reference
+    over 8n points."""
+    import torch
+    import zkvm_amd
+    from zkvm_amd import api, circuits
+    n = 1 << 17
+    c = circuits.widget_circuit(n)
+    c["selectors"][11:15] = np.stack([orc.sigma_to_lagrange(c["sigma_map"][k]) for k in range(4)])
+    own = zkvm_amd.Context(0)      # the module's context keeps its 2^20-point SRS
+    try:
+        own.srs_load(srs20["xy"][:n + 7])
+        gp = api.Prover(own, n, c["constraints"], c["selectors"].reshape(-1, 4), b"headline-widgets", c["pi_indexes"])
+        bl = circuits.random_blinders(17)
+        wires = torch.from_numpy(c["wires"].reshape(-1, 4).view(np.int64)).cuda()
+        got = gp.prove(wires, c["public_inputs"], bl)
+        assert got["coset"] == 4
+    finally:
+        own.close()
+    op = orc.Prover(n, c["constraints"], c["selectors"], srs20["xy"][:n + 7], b"headline-widgets", c["pi_indexes"], threads=16)
+    assert op.preprocess_rc == 0
     want = op.prove(c["wires"], c["public_inputs"], bl)
     assert want["rc"] == 0
     for key in ("challenges", "evals", "comms_inf", "comms"):

@@ -196,6 +196,10 @@ int zkgpu_commit_many(zkgpu_ctx *ctx, uint32_t count, const uint64_t *const *coe
 /* Host-only self-check of the Montgomery product the kernels are built on (the same source compiles for host and
  * device): field 0 = Fr (4 limbs per element), 1 = Fq (6 limbs); out[i] = a[i] * b[i] for count elements. */
 int zkgpu_field_mul_selfcheck(int field, const uint64_t *a, const uint64_t *b, size_t count, uint64_t *out);
+/* The same for the host's inversion (binary extended Euclidean algorithm on 64-bit words; the host inverts once per
+ * commitment batch and per permutation, where the reference calls Fp::invert / Scalar::invert, fp.rs:383-415 and
+ * scalar.rs:394-477): out[i] = a[i]^-1 in Montgomery form, zero for zero. */
+int zkgpu_field_inv_selfcheck(int field, const uint64_t *a, size_t count, uint64_t *out);
 
 /* Host-only self-check of the bucket arithmetic used inside the MSM kernels (28-bit unsaturated limbs, extended
  * Jacobian mixed additions): adds the n affine points in order, point i negated when negate[i] != 0, and returns the

@@ -86,6 +86,7 @@ extern "C" {
     pub fn zkgpu_commit_many(ctx: *mut zkgpu_ctx, count: u32, coeffs: *const *const u64, lens: *const usize, out_xy: *mut u64,
                              out_infinity: *mut u8) -> c_int;
     pub fn zkgpu_field_mul_selfcheck(field: c_int, a: *const u64, b: *const u64, count: usize, out: *mut u64) -> c_int;
+    pub fn zkgpu_field_inv_selfcheck(field: c_int, a: *const u64, count: usize, out: *mut u64) -> c_int;
     pub fn zkgpu_g1_bucket_selfcheck(xy: *const u64, infinity: *const u8, negate: *const u8, n: usize, out_xyz: *mut u64,
                                      violations: *mut u64) -> c_int;
     pub fn zkgpu_g1_bucket_selfcheck_tree(xy: *const u64, infinity: *const u8, negate: *const u8, n: usize,

@@ -32,3 +32,20 @@ def test_fq_product(orc):
     b = np.concatenate([np.tile(e, (len(e), 1)), rnd[1000:]])
     got = api.field_mul_selfcheck(1, a, b)
     assert np.array_equal(got, orc.fq_op("mul", a, b))
+
+
+def test_host_inversions(orc):
+    """The host's inversions (Fp::invert fp.rs:383-415, Scalar::invert scalar.rs:394-477: a^(p-2) there, the binary
+    extended Euclidean algorithm here) against the oracle's: same canonical result, zero for zero."""
+    from zkvm_amd import api
+    fr = np.concatenate([_edge(M.R_MOD, 4, lambda v: M.int_to_limbs(v, 4)), M.random_fr_mont(400, seed=12)])
+    got = api.field_inv_selfcheck(0, fr)
+    assert np.array_equal(got, orc.fr_op("invert", fr))
+    nz = fr.any(axis=1)
+    assert not got[~nz].any()
+    assert np.array_equal(api.field_mul_selfcheck(0, fr[nz], got[nz]), np.tile(M.fr_to_mont(1), (int(nz.sum()), 1)))
+    rng = np.random.Generator(np.random.PCG64(6))
+    rnd = rng.integers(0, 1 << 64, size=(300, 6), dtype=np.uint64)
+    rnd[:, 5] %= np.uint64(0x1a0111ea397fe69a)
+    fq = np.concatenate([_edge(M.P_MOD, 6, lambda v: M.int_to_limbs(v, 6)), rnd])
+    assert np.array_equal(api.field_inv_selfcheck(1, fq), orc.fq_op("invert", fq))

@@ -76,6 +76,7 @@ SIGNATURES = {
     "zkgpu_msm_profile_dev": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "zkgpu_msm_set_params": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "zkgpu_field_mul_selfcheck": (C.c_int, [C.c_int, _P, _P, C.c_size_t, _P]),
+    "zkgpu_field_inv_selfcheck": (C.c_int, [C.c_int, _P, C.c_size_t, _P]),
     "zkgpu_g1_bucket_selfcheck": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P]),
     "zkgpu_g1_bucket_selfcheck_tree": (C.c_int, [_P, _P, _P, C.c_size_t, _P, _P]),
     "zkgpu_prover_set_sharding": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, _P, _P]),

@@ -287,6 +287,17 @@ def field_mul_selfcheck(field, a, b):
     return out
 
 
+def field_inv_selfcheck(field, a):
+    """Host-side run of the library's field inversion (Montgomery form in and out): field 0 = Fr (n, 4), 1 = Fq (n, 6)."""
+    width = 4 if field == 0 else 6
+    x = _np_u64(a, width)
+    out = np.zeros_like(x)
+    rc = _lib.lib().zkgpu_field_inv_selfcheck(int(field), x.ctypes.data, x.shape[0], out.ctypes.data)
+    if rc != 0:
+        raise ZkGpuError(rc, "field_inv_selfcheck")
+    return out
+
+
 def g1_bucket_selfcheck(xy, negate=None, infinity=None, tree=False):
     """Host-side run of the MSM kernels' bucket arithmetic -> (projective sum (18,), bound violations); `tree` sums
     accumulators pairwise as the bucket reduction does instead of adding the points one by one."""

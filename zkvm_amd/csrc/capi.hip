@@ -525,6 +525,24 @@ int zkgpu_field_mul_selfcheck(int field, const uint64_t *a, const uint64_t *b, s
     return ZKGPU_OK;
 }
 
+int zkgpu_field_inv_selfcheck(int field, const uint64_t *a, size_t count, uint64_t *out) {
+    if ((field != 0 && field != 1) || ((!a || !out) && count)) return ZKGPU_ERR_INVALID_ARG;
+    for (size_t i = 0; i < count; i++) {
+        if (field == 0) {
+            Fr x;
+            memcpy(&x, a + 4 * i, sizeof x);
+            const Fr z = Fr::inv(x);
+            memcpy(out + 4 * i, &z, sizeof z);
+        } else {
+            Fq x;
+            memcpy(&x, a + 6 * i, sizeof x);
+            const Fq z = Fq::inv(x);
+            memcpy(out + 6 * i, &z, sizeof z);
+        }
+    }
+    return ZKGPU_OK;
+}
+
 int zkgpu_g1_bucket_selfcheck(const uint64_t *xy, const uint8_t *infinity, const uint8_t *negate, size_t n,
                               uint64_t out_xyz[18], uint64_t *violations) {
     if ((!xy && n) || !out_xyz) return ZKGPU_ERR_INVALID_ARG;

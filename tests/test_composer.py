@@ -324,6 +324,18 @@ def test_gpu_proof_with_every_widget_in_one_key(orc, subset):
             assert ctx._lib.zkgpu_prover_last_proof_coset(ctx._h) in (0, 8)
         again = gp.prove(circ["wires"].reshape(-1, 4), circ["public_inputs"], bl)     # and the key still proves over 4n
         assert again["coset"] == 4 and np.array_equal(again["comms"], want["comms"])
+        if subset == (0, 1, 2, 3):
+            # a clone of the context (zkgpu_ctx_clone) proves with the same resident key, widget selectors included
+            twin = ctx.clone()
+            try:
+                cloned = gp.on(twin).prove(circ["wires"].reshape(-1, 4), circ["public_inputs"], bl)
+                assert cloned["coset"] == 4
+                for key in ("challenges", "evals", "comms_inf", "comms"):
+                    assert np.array_equal(cloned[key], want[key]), key
+                with pytest.raises(api.PolynomialDegreeTooLarge):
+                    gp.on(twin).prove(_violate_one_widget(circ, 2).reshape(-1, 4), circ["public_inputs"], bl)
+            finally:
+                twin.close()
         if subset in ((0, 1, 2, 3), (1, 3)):
             # the reference's byte format (its 8n vectors are built for it on demand) and a key restored from it
             blob = gp.to_bytes()

@@ -505,7 +505,10 @@ def run_prove(args, rank, world, local, device):
     ctx.sync()
     t_srs = time.perf_counter() - t0
     t0 = time.perf_counter()
-    circ = circuits.arithmetic_circuit(n, seed=5 if sharded else 5 + rank)
+    # `--circuit widgets` (one GPU): the timed proofs themselves are those of a key with every widget, e.g. for a
+    # kernel trace or counter passes of its quotient kernels; the line's config says so
+    widgets_main = args.circuit == "widgets" and world == 1 and n >= (1 << 14)
+    circ = circuits.widget_circuit(n) if widgets_main else circuits.arithmetic_circuit(n, seed=5 if sharded else 5 + rank)
     circuits.fill_sigma_rows(circ, ctx)
     t_circ = time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -539,6 +542,9 @@ def run_prove(args, rank, world, local, device):
             " (every second point of the reference's 8n coset; the seven top coefficients of the quotient restored from "
             "those of the round polynomials: the same coefficients)" if timed["coset"] == 4 else " (the reference's coset)")
         quot = quotient_roofline(ctx, n, timed["coset"])
+        if widgets_main:   # the time spans the four widget launches as well; their own roofline is in the `widgets` record
+            quot["kernel"] = "quotient of a key with every widget: quotient_widget_kernel<0..3> + " + quot["kernel"]
+            quot["note"] = "streams and products counted for the arithmetic and permutation launch only"
         # dominant kernel: msm_accumulate_kernel of the 11 commitments; HIP events on the library's stream around the
         # phases of one n-point commitment
         n_local = count if sharded else n      # points this GPU holds
@@ -891,7 +897,8 @@ def main():
     ap.add_argument("--no-sub-records", action="store_true",
                     help="prove workload: leave out the msm / ntt / msm_scaling / sharded_prove records")
     ap.add_argument("--circuit", default="arithmetic", choices=["arithmetic", "widgets"],
-                    help="prove workload: `widgets` keeps the sub-record of a key with every widget even under --no-widget-record")
+                    help="prove workload: `widgets` times proofs of a key with every widget instead of the arithmetic circuit (one GPU) and "
+                         "keeps the widget sub-record even under --no-widget-record")
     ap.add_argument("--no-widget-record", action="store_true", help="prove workload: leave out the widget-key record")
     ap.add_argument("--full-coset", action="store_true",
                     help="prove workload: evaluate the quotient over the reference's 8n coset even where 4n points suffice")
@@ -915,6 +922,8 @@ def main():
                 "config": {"workload": "full PLONK prove, 2^%d gates (wire commits, permutation Z, quotient, "
                                        "linearization, openings), bit-exact vs the CPU prover" % args.log_gates,
                            "n": 1 << args.log_gates, "parallelism": "independent proofs per GPU"}}
+        if args.circuit == "widgets" and world == 1 and args.log_gates >= 14:
+            line["config"]["workload"] += "; circuit: every widget in use (zkvm_amd.circuits.widget_circuit)"
         if args.sharded and world > 1:
             line["scaling"] = "strong"
             line["config"]["parallelism"] = ("one proof on %d GPUs: SRS point ranges per GPU, 144-byte partial sums "

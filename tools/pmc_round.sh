@@ -1,6 +1,6 @@
 #!/bin/bash
 # All hardware-counter passes a round's documents quote, in one GPU call:  tools/pmc_round.sh <tag>
-#   gpurun_out/<tag>_pmc_{ntt,msm20,msm24,prove,prove_8n}.csv   (tools/pmc.sh passes, summarised by tools/pmc_summary.py)
+#   gpurun_out/<tag>_pmc_{ntt,msm20,msm24,prove,prove_8n,widgets}.csv   (tools/pmc.sh passes, summarised by tools/pmc_summary.py)
 set -e
 tag=${1:-rXX}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -11,7 +11,8 @@ tools/pmc.sh msm20 --workload msm --log-points 20 $common
 tools/pmc.sh msm24 --workload msm --log-points 24 $common
 tools/pmc.sh prove $common
 tools/pmc.sh prove_8n $common --full-coset
-for t in ntt msm20 msm24 prove prove_8n; do
+tools/pmc.sh widgets $common --circuit widgets
+for t in ntt msm20 msm24 prove prove_8n widgets; do
   python3 tools/pmc_summary.py gpurun_out/pmc_$t > gpurun_out/${tag}_pmc_$t.csv
   echo "$t: $(wc -l < gpurun_out/${tag}_pmc_$t.csv) rows"
 done

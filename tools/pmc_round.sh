@@ -1,5 +1,5 @@
 #!/bin/bash
-# All hardware-counter passes a round's documents quote, in one GPU call:  tools/pmc_round.sh <tag>
+# All hardware-counter passes that the documents quote, in one GPU call:  tools/pmc_round.sh <tag>
 #   gpurun_out/<tag>_pmc_{ntt,msm20,msm24,prove,prove_8n,widgets}.csv   (tools/pmc.sh passes, summarised by tools/pmc_summary.py)
 set -e
 tag=${1:-rXX}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The measurements a round's documents quote, in one GPU call:  tools/round_measure.sh <tag>
+# The measurements that the documents quote, in one GPU call:  tools/round_measure.sh <tag>
 #   gpurun_out/<tag>_bench_{prove,msm,ntt}.json   the three bench lines (prove with its CPU baseline leg)
 #   gpurun_out/<tag>_bench_prove_8n.json          the proof forced over the reference's 8n coset, for comparison
 #   gpurun_out/<tag>_small_proofs.txt             ms per proof at 2^10 .. 2^18 gates

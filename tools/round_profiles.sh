@@ -1,5 +1,5 @@
 #!/bin/bash
-# Bench lines, kernel-trace summaries, the proof's timeline and the measured CPU baseline of a round in one GPU call (one
+# Bench lines, kernel-trace summaries, the proof's timeline and the measured CPU baseline in one GPU call (one
 # box: the times belong together):  tools/round_profiles.sh <tag>   -> gpurun_out/<tag>_*
 set -e
 tag=${1:-rXX}
